@@ -1,0 +1,242 @@
+"""Synthetic checkpoints and inputs for the hot path (no real checkpoint or image ships with the
+reference: SURVEY.md section 8d).
+
+* `state_dict_spec(opt_coarse, opt_fine)` enumerates the reference's state-dict keys and shapes for
+  `PIFuMRNet(opt, netG=PIFuNetwNML(opt_netG))` (key scheme: `reconstruction.py:285-292`,
+  `Filter.py:133-185`, `MLP.py:30-41`, `networks.py:131-207`).
+* `name_seeded_state_dict(...)` fills every key from a generator seeded by FNV-1a64(key) ^ seed, so
+  the reference (golden generator), the oracle and the HIP path all see identical tensors without a
+  checkpoint file travelling anywhere.  Distribution mirrors `net_util.py:10-32` (conv ~ N(0, s),
+  BatchNorm2d weight ~ N(1, 0.02)); `perturb=True` additionally randomises biases, affine norm
+  parameters and BN running stats so that parity tests exercise those terms.
+* `synthetic_inputs(...)` builds the `gen_mesh` data dict of `readData.py:106-116`.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+
+_FNV_OFFSET = 0xCBF29CE484222325
+_FNV_PRIME = 0x100000001B3
+
+
+def fnv1a64(text: str) -> int:
+    h = _FNV_OFFSET
+    for byte in text.encode('utf-8'):
+        h ^= byte
+        h = (h * _FNV_PRIME) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+# ----------------------------------------------------------------------------- key/shape spec
+def _norm2d_keys(prefix, ch, norm, out):
+    out[prefix + '.weight'] = (ch,)
+    out[prefix + '.bias'] = (ch,)
+    if norm == 'batch':
+        out[prefix + '.running_mean'] = (ch,)
+        out[prefix + '.running_var'] = (ch,)
+        out[prefix + '.num_batches_tracked'] = ()
+
+
+def _convblock_keys(prefix, cin, cout, norm, out):
+    out[prefix + '.conv1.weight'] = (cout // 2, cin, 3, 3)
+    out[prefix + '.conv2.weight'] = (cout // 4, cout // 2, 3, 3)
+    out[prefix + '.conv3.weight'] = (cout // 4, cout // 4, 3, 3)
+    _norm2d_keys(prefix + '.bn1', cin, norm, out)
+    _norm2d_keys(prefix + '.bn2', cout // 2, norm, out)
+    _norm2d_keys(prefix + '.bn3', cout // 4, norm, out)
+    _norm2d_keys(prefix + '.bn4', cin, norm, out)
+    if cin != cout:
+        _norm2d_keys(prefix + '.downsample.0', cin, norm, out)   # alias of bn4 (Filter.py:48-49)
+        out[prefix + '.downsample.2.weight'] = (cout, cin, 1, 1)
+
+
+def _hourglass_keys(prefix, level, feat, norm, out):
+    _convblock_keys(f'{prefix}.b1_{level}', feat, feat, norm, out)
+    _convblock_keys(f'{prefix}.b2_{level}', feat, feat, norm, out)
+    if level > 1:
+        _hourglass_keys(prefix, level - 1, feat, norm, out)
+    else:
+        _convblock_keys(f'{prefix}.b2_plus_{level}', feat, feat, norm, out)
+    _convblock_keys(f'{prefix}.b3_{level}', feat, feat, norm, out)
+
+
+def filter_keys(prefix, n_stack, depth, in_ch, last_ch, norm, down_type, out):
+    """Keys of the reference `Filter` (HGFilter), `Filter.py:133-185`."""
+    if down_type not in ('ave_pool', 'no_down'):
+        raise NameError('unknown downsampling type')       # Filter.py:197
+    out[prefix + '.conv1.weight'] = (64, in_ch, 7, 7)
+    out[prefix + '.conv1.bias'] = (64,)
+    _norm2d_keys(prefix + '.bn1', 64, norm, out)
+    _convblock_keys(prefix + '.conv2', 64, 128, norm, out)
+    _convblock_keys(prefix + '.conv3', 128, 128, norm, out)
+    _convblock_keys(prefix + '.conv4', 128, 256, norm, out)
+    for s in range(n_stack):
+        _hourglass_keys(f'{prefix}.m{s}', depth, 256, norm, out)
+        _convblock_keys(f'{prefix}.top_m_{s}', 256, 256, norm, out)
+        out[f'{prefix}.conv_last{s}.weight'] = (256, 256, 1, 1)
+        out[f'{prefix}.conv_last{s}.bias'] = (256,)
+        _norm2d_keys(f'{prefix}.bn_end{s}', 256, norm, out)
+        out[f'{prefix}.l{s}.weight'] = (last_ch, 256, 1, 1)
+        out[f'{prefix}.l{s}.bias'] = (last_ch,)
+        if s < n_stack - 1:
+            out[f'{prefix}.bl{s}.weight'] = (256, 256, 1, 1)
+            out[f'{prefix}.bl{s}.bias'] = (256,)
+            out[f'{prefix}.al{s}.weight'] = (256, last_ch, 1, 1)
+            out[f'{prefix}.al{s}.bias'] = (256,)
+
+
+def mlp_keys(prefix, dims, res_layers, norm, out):
+    """Keys of the reference `MLP` (SurfaceClassifier), `MLP.py:30-41`."""
+    n = len(dims) - 1
+    for i in range(n):
+        cin = dims[i] + (dims[0] if i in res_layers else 0)
+        out[f'{prefix}.filters.{i}.weight'] = (dims[i + 1], cin, 1)
+        out[f'{prefix}.filters.{i}.bias'] = (dims[i + 1],)
+    for i in range(n - 1):
+        if norm == 'group':
+            out[f'{prefix}.norms.{i}.weight'] = (dims[i + 1],)
+            out[f'{prefix}.norms.{i}.bias'] = (dims[i + 1],)
+        elif norm == 'batch':
+            _norm2d_keys(f'{prefix}.norms.{i}', dims[i + 1], 'batch', out)
+
+
+def global_generator_keys(prefix, in_nc, out_nc, ngf, n_down, n_blocks, out):
+    """Keys of pix2pixHD `GlobalGenerator` with InstanceNorm(affine=False), `networks.py:131-165`."""
+    out[f'{prefix}.model.1.weight'] = (ngf, in_nc, 7, 7)
+    out[f'{prefix}.model.1.bias'] = (ngf,)
+    idx = 4
+    for i in range(n_down):
+        c = ngf * 2 ** i
+        out[f'{prefix}.model.{idx}.weight'] = (2 * c, c, 3, 3)
+        out[f'{prefix}.model.{idx}.bias'] = (2 * c,)
+        idx += 3
+    c = ngf * 2 ** n_down
+    for _ in range(n_blocks):
+        for j in (1, 5):
+            out[f'{prefix}.model.{idx}.conv_block.{j}.weight'] = (c, c, 3, 3)
+            out[f'{prefix}.model.{idx}.conv_block.{j}.bias'] = (c,)
+        idx += 1
+    for i in range(n_down):
+        c = ngf * 2 ** (n_down - i)
+        out[f'{prefix}.model.{idx}.weight'] = (c, c // 2, 3, 3)      # ConvTranspose2d: (in, out, k, k)
+        out[f'{prefix}.model.{idx}.bias'] = (c // 2,)
+        idx += 3
+    out[f'{prefix}.model.{idx + 1}.weight'] = (out_nc, ngf, 7, 7)
+    out[f'{prefix}.model.{idx + 1}.bias'] = (out_nc,)
+
+
+def image_filter_in_channels(opt_coarse) -> int:
+    c = int(getattr(opt_coarse, 'in_image_channels', 3))
+    if getattr(opt_coarse, 'use_front_normal', False):
+        c += 3
+    if getattr(opt_coarse, 'use_back_normal', False):
+        c += 3
+    return c
+
+
+def coarse_spec(opt, prefix='') -> 'OrderedDict[str, tuple]':
+    """State-dict spec of `PIFuNetwNML(opt)` (`PIFuNetwNML.py:31-67`)."""
+    out = OrderedDict()
+    p = prefix
+    filter_keys(p + 'image_filter', opt.num_stack, opt.hg_depth, image_filter_in_channels(opt),
+                opt.hg_dim, opt.norm, opt.hg_down, out)
+    mlp_keys(p + 'mlp', opt.mlp_dim, opt.mlp_res_layers, opt.mlp_norm, out)
+    cimg = int(getattr(opt, 'in_image_channels', 3))
+    if getattr(opt, 'use_front_normal', False):
+        global_generator_keys(p + 'netF', cimg, 3, 64, 4, 9, out)
+    if getattr(opt, 'use_back_normal', False):
+        global_generator_keys(p + 'netB', cimg, 3, 64, 4, 9, out)
+    return out
+
+
+def state_dict_spec(opt_coarse, opt_fine) -> 'OrderedDict[str, tuple]':
+    """State-dict spec of `PIFuMRNet(opt_fine, netG=PIFuNetwNML(opt_coarse))` (`PIFuMRNet.py:29-55`)."""
+    out = OrderedDict()
+    filter_keys('image_filter', opt_fine.num_stack, opt_fine.hg_depth,
+                image_filter_in_channels(opt_coarse), opt_fine.hg_dim, opt_fine.norm, 'no_down', out)
+    mlp_keys('mlp', opt_fine.mlp_dim, opt_fine.mlp_res_layers, opt_fine.mlp_norm, out)
+    out.update(coarse_spec(opt_coarse, 'netG.'))
+    return out
+
+
+# ----------------------------------------------------------------------------- values
+def _is_norm_key(key: str) -> bool:
+    parts = key.split('.')
+    owner = parts[-2] if len(parts) >= 2 else ''
+    return (owner.startswith('bn') or owner == '0' and 'downsample' in key or 'norms' in parts)
+
+
+def name_seeded_tensor(key: str, shape, seed: int = 0, conv_std: float = 0.02,
+                       mlp_std: float | None = None, perturb: bool = False) -> torch.Tensor:
+    gen = torch.Generator().manual_seed((fnv1a64(key) ^ seed) & 0x7FFFFFFFFFFFFFFF)
+    leaf = key.rsplit('.', 1)[-1]
+    if leaf == 'num_batches_tracked':
+        return torch.zeros((), dtype=torch.int64)
+    shape = tuple(shape)
+    is_norm = _is_norm_key(key)
+    is_mlp = '.filters.' in key or key.startswith('filters.')
+    if leaf == 'weight' and not is_norm:
+        std = mlp_std if (is_mlp and mlp_std is not None) else conv_std
+        return torch.randn(shape, generator=gen) * std
+    if leaf == 'weight' and is_norm:
+        is_bn2d = 'norms' not in key.split('.')
+        if is_bn2d or perturb:
+            return 1.0 + 0.02 * torch.randn(shape, generator=gen) * (5.0 if perturb else 1.0)
+        return torch.ones(shape)
+    if leaf == 'bias':
+        if perturb:
+            return 0.05 * torch.randn(shape, generator=gen)
+        return torch.zeros(shape)
+    if leaf == 'running_mean':
+        return 0.1 * torch.randn(shape, generator=gen) if perturb else torch.zeros(shape)
+    if leaf == 'running_var':
+        return 0.5 + torch.rand(shape, generator=gen) if perturb else torch.ones(shape)
+    raise KeyError(f'unrecognised state-dict leaf in {key!r}')
+
+
+def name_seeded_state_dict(spec, seed: int = 0, conv_std: float = 0.02, mlp_std: float | None = None,
+                           perturb: bool = False) -> 'OrderedDict[str, torch.Tensor]':
+    sd = OrderedDict()
+    for key, shape in spec.items():
+        sd[key] = name_seeded_tensor(key, shape, seed, conv_std, mlp_std, perturb)
+    # the ConvBlock shortcut norm is the same module object as bn4 (Filter.py:41,48-49)
+    for key in list(sd):
+        if '.downsample.0.' in key:
+            sd[key] = sd[key.replace('.downsample.0.', '.bn4.')]
+    return sd
+
+
+# ----------------------------------------------------------------------------- inputs
+def synthetic_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor:
+    """[1, C, size, size] in [-1, 1]: low-frequency sinusoids + U(-0.1, 0.1) noise."""
+    gen = torch.Generator().manual_seed(0x5EED0000 + seed)
+    lin = torch.linspace(-1.0, 1.0, size)
+    yy, xx = torch.meshgrid(lin, lin, indexing='ij')
+    img = torch.empty(1, channels, size, size)
+    for c in range(channels):
+        fx, fy, ph = (1.5 + c + 0.37 * seed), (2.25 - 0.5 * c + 0.21 * seed), 0.7 * c + seed
+        img[0, c] = 0.6 * torch.sin(math.pi * fx * xx + ph) * torch.cos(math.pi * fy * yy - 0.5 * ph)
+        img[0, c] += 0.25 * torch.exp(-((xx - 0.1 * c) ** 2 + (yy + 0.05 * c) ** 2) * 4.0)
+    img += (torch.rand(img.shape, generator=gen) - 0.5) * 0.2
+    return img.clamp_(-1.0, 1.0)
+
+
+def synthetic_inputs(load_size: int = 1024, channels: int = 3, seed: int = 0) -> dict:
+    """Data dict with the keys `gen_mesh` reads (`readData.py:106-116`, `reconstruction.py:29-34`)."""
+    img = synthetic_image(load_size, channels, seed)
+    if load_size == 512:
+        img_512 = img.clone()
+    else:
+        img_512 = torch.nn.functional.interpolate(img, size=(512, 512), mode='bilinear',
+                                                  align_corners=False)
+    calib = torch.eye(4)
+    calib[1, 1] = -1.0                                   # readData.py:90-92
+    return {
+        'name': f'synthetic_{seed}',
+        'img': img, 'img_512': img_512,
+        'calib': calib.unsqueeze(0),
+        'b_min': [-1, -1, -1], 'b_max': [1, 1, 1],
+    }

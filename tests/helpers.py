@@ -1,0 +1,44 @@
+"""Seed-derived inputs shared by the golden generator (tests/golden/make_golden.py) and the tests."""
+import numpy as np
+import torch
+
+import pifuhd_amd  # noqa: F401
+from pifuhd_amd import config, synth
+
+
+def seeded_features(seed, hc=32, hf=64):
+    g = torch.Generator().manual_seed(1000 + seed)
+    fc = torch.randn(1, 256, hc, hc, generator=g)
+    ff = torch.randn(1, 16, hf, hf, generator=g)
+    return fc, ff
+
+
+def seeded_points(seed, n, lim=1.15):
+    g = torch.Generator().manual_seed(2000 + seed)
+    return (torch.rand(1, 3, n, generator=g) * 2 - 1) * lim
+
+
+def calib_tensor():
+    c = torch.eye(4)
+    c[1, 1] = -1.0
+    return c[None]
+
+
+def golden_nets(mlp_norm='group', seed=1, mlp_std=0.16, perturb=True, norm='batch'):
+    """Options + name-seeded state dict exactly as make_golden.build_reference() loads them."""
+    if mlp_norm not in ('group', 'batch') and mlp_std is not None:
+        mlp_std = 0.04
+    oc = config.coarse_opt(mlp_norm=mlp_norm, norm=norm)
+    of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=seed, mlp_std=mlp_std,
+                                      perturb=perturb)
+    return sd, oc, of
+
+
+def noisy_field(points):
+    """The deterministic analytic field used by make_golden.golden_octree()."""
+    p = np.asarray(points).astype(np.float32).astype(np.float64)
+    r = np.sqrt((0.8 * p[0]) ** 2 + (0.45 * p[1]) ** 2 + (1.6 * p[2]) ** 2)
+    v = 1.0 / (1.0 + np.exp(-(0.35 - r) / 0.05))
+    v = v + 0.02 * np.sin(37.0 * p[0] + 11.0 * p[1]) * np.cos(23.0 * p[2])
+    return v.astype(np.float32)
