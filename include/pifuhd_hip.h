@@ -1,0 +1,146 @@
+/* pifuhd_hip.h -- C ABI of the MI355X-native PIFuHD occupancy-query + meshing hot path.
+ *
+ * The reference (agnJason/RGB-D-PIFuHD) has no FFI/plugin boundary: its hot path is plain Python over
+ * PyTorch ops.  This header is therefore the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md); every entry point names the reference code it replaces (file:line relative to the
+ * reference root).  Conventions:
+ *   - every function returns 0 (PIFU_OK) or a negative PIFU_ERR_* code; pifu_last_error() gives the
+ *     message of the last failure on the calling thread; nothing throws across the boundary;
+ *   - the CALLER owns every buffer (device pointers unless a parameter says "host"); the library owns
+ *     only the opaque context (packed weights, NHWC feature maps, workspaces);
+ *   - all kernels are enqueued on the caller's stream (a hipStream_t passed as void*); only the calls
+ *     documented as "synchronises" wait for the device;
+ *   - fp32 network arithmetic (exact-fp32 MFMA), float64 grid bookkeeping, as in the reference.
+ */
+#ifndef PIFUHD_HIP_H
+#define PIFUHD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pifu_ctx pifu_ctx;
+typedef void *pifu_stream;                 /* hipStream_t */
+
+enum {
+    PIFU_OK = 0,
+    PIFU_ERR_INVALID = -1,                 /* bad argument / shape */
+    PIFU_ERR_HIP = -2,                     /* a HIP runtime call failed */
+    PIFU_ERR_STATE = -3,                   /* call order violated (e.g. query before features) */
+    PIFU_ERR_NOMEM = -4,                   /* workspace too small and cannot grow */
+    PIFU_ERR_MC_LEVEL = -5,                /* "Surface level must be within volume data range." */
+    PIFU_ERR_MC_EMPTY = -6                 /* "No surface found at the given iso value." */
+};
+
+enum { PIFU_LEVEL_COARSE = 0, PIFU_LEVEL_FINE = 1 };
+
+/* MLP normalisation modes (reference: MLP.py:37-41,65-69; train/eval quirk SURVEY C-2) */
+enum {
+    PIFU_NORM_NONE = 0,                    /* leaky_relu only                                  */
+    PIFU_NORM_GROUP = 1,                   /* GroupNorm(32, C): statistics over (C/32 x chunk) */
+    PIFU_NORM_BATCH_EVAL = 2,              /* BatchNorm1d with running statistics              */
+    PIFU_NORM_BATCH_TRAIN = 3              /* BatchNorm1d with per-chunk batch statistics      */
+};
+
+/* pifu_query flags */
+enum {
+    PIFU_Q_COARSE_ONLY = 1,                /* PIFuNetwNML.query only (PIFuNetwNML.py:99-141)            */
+    PIFU_Q_NO_FINE_MASK = 2,               /* calc_normal: fine prediction not masked (PIFuMRNet.py:223-230) */
+    PIFU_Q_FULL_COARSE = 4                 /* run the coarse MLP to its last layer even if pred_coarse is NULL (the
+                                              reference always does: netG.query inside PIFuMRNet.query) */
+};
+
+const char *pifu_last_error(void);
+int pifu_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int pifu_ctx_create(int device, pifu_ctx **out);
+int pifu_ctx_destroy(pifu_ctx *ctx);
+/* Pre-size the query workspace for `rows` padded point rows (growth otherwise happens lazily, outside
+ * the timed region after the first call).  Synchronises. */
+int pifu_reserve(pifu_ctx *ctx, int64_t rows);
+int64_t pifu_workspace_bytes(pifu_ctx *ctx);
+
+/* ---- SurfaceClassifier definition: replaces MLP.__init__ / load_state_dict (MLP.py:12-41) ---- */
+/* dims = filter_channels, res_layers = skip-concat layers, merge_layer as passed to MLP() (<=0 means
+ * len(dims)/2, MLP.py:25), norm = PIFU_NORM_*.  Level FINE consumes [fine features | coarse phi]. */
+int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, int ndims,
+                    const int32_t *res_layers, int nres, int merge_layer, int norm);
+/* weight [Cout][Cin] (Conv1d k=1 weight squeezed), bias [Cout]; norm_weight/norm_bias [Cout] or NULL
+ * (last layer / PIFU_NORM_NONE); running_mean/var only for the batch modes.  Host pointers. */
+int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight, const float *bias,
+                       const float *norm_weight, const float *norm_bias,
+                       const float *running_mean, const float *running_var);
+/* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
+ * z_div = z_size of the COARSE net's options. */
+int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);
+
+/* ---- feature maps: the output of filter()/filter_global()/filter_local() -------------------- */
+/* feat: device fp32 NCHW [1][C][H][W] (PIFuNetwNML.py:94-97, PIFuMRNet.py:114-117).  Repacked to NHWC
+ * inside the context so that one bilinear tap is one contiguous channel row. */
+int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, int H, int W,
+                      pifu_stream stream);
+
+/* ---- query: PIFuMRNet.query / PIFuNetwNML.query (PIFuMRNet.py:119-186, PIFuNetwNML.py:99-141) - */
+/* points: device fp32 [3][n] (the reference's [1,3,N] tensor); calib: HOST fp32 4x4 row-major;
+ * `chunk` = number of points the reference would pass per query() call (GroupNorm couples the points
+ * of one call: SURVEY C-1); the n points are treated as consecutive calls of `chunk` points, remainder
+ * last (mesh_util.py:98-114).  Outputs (device, may be NULL): pred_fine [n] = net.get_preds()[0][0],
+ * pred_coarse [n] = netG.preds[0][0], phi [Cphi][n] = netG.phi[0] (only when n <= chunk). */
+int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib, int64_t chunk,
+               int flags, float *pred_fine, float *pred_coarse, float *phi, pifu_stream stream);
+
+/* ---- lattice evaluation: create_grid + calib^-1 + eval_func (mesh_util.py:12-38,59-74) -------- */
+/* Evaluates `count` points of the C-ordered lattice res[0] x res[1] x res[2] over [-1,1)^3
+ * (point (i,j,k) = -1 + (i,j,k) * 2/res, float64, then calib_inv (HOST float64 4x4), then cast to
+ * float32 exactly like mesh_util.py:61-70) and writes fp32 predictions.  The points are the flat
+ * indices first, first+1, ... when `index` is NULL, else index[first .. first+count) (device int64).
+ * Chunks are cut relative to `first`, so `first` must be a multiple of `chunk` for parity. */
+int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_inv, const float *calib,
+                      const int64_t *index, int64_t first, int64_t count, int64_t chunk, int flags,
+                      float *pred, pifu_stream stream);
+
+/* ---- octree bookkeeping: eval_grid_octree (mesh_util.py:124-187), order-free form */
+/* state: sdf float64 [R^3] and notprocessed uint8 [R^3], both device, caller-owned. */
+int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *notprocessed, pifu_stream stream);
+/* Ordered (C-order) compaction of lattice(reso) & notprocessed into index_out (device int64, capacity
+ * cap); *count_host receives the number of test points.  Synchronises the stream. */
+int pifu_octree_select(pifu_ctx *ctx, int R, int reso, const uint8_t *notprocessed,
+                       int64_t *index_out, int64_t cap, int64_t *count_host, pifu_stream stream);
+/* Scatter the evaluated values, clear notprocessed there, then (if reso > 1) the 8-corner min/max test
+ * with `threshold` and the inclusive block fill, bit-exact with the reference's sequential loop. */
+int pifu_octree_commit(pifu_ctx *ctx, int R, int reso, double threshold, const int64_t *index,
+                       const float *values, int64_t count, double *sdf, uint8_t *notprocessed,
+                       pifu_stream stream);
+/* Convenience single-GPU driver of the three calls above + pifu_eval_lattice; dense when
+ * init_resolution <= 0 (eval_grid, mesh_util.py:116-120).  *n_evaluated (host) = points evaluated. */
+int pifu_eval_grid(pifu_ctx *ctx, int R, const double *calib_inv, const float *calib, int64_t chunk,
+                   int init_resolution, double threshold, int flags, double *sdf, uint8_t *notprocessed,
+                   int64_t *n_evaluated, pifu_stream stream);
+
+/* ---- marching cubes: skimage.measure.marching_cubes_lewiner as called at mesh_util.py:84 ------- */
+/* volume: device [n0][n1][n2], dtype 0 = float32, 1 = float64 (cast to float32 first, as skimage does).
+ * pifu_mc_count classifies every cell (33-case Lewiner tables + ambiguity tests) and prefix-sums vertex
+ * and triangle counts in the serial scan order; it synchronises and returns the totals, or
+ * PIFU_ERR_MC_LEVEL / PIFU_ERR_MC_EMPTY for the two exceptions skimage raises.  pifu_mc_emit then writes
+ * verts fp32 [nv][3] (array-axis order) and faces int32 [nf][3] ('descent' order), bit-exact. */
+int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level,
+                  int64_t *nverts, int64_t *nfaces, pifu_stream stream);
+int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream);
+
+/* ---- per-vertex normals: PIFuMRNet.calc_normal (PIFuMRNet.py:188-243) as used by gen_mesh -------- */
+/* verts: device fp32 [3][n]; every call is ONE GroupNorm batch of 4n points (p, p+dx, p+dy, p+dz
+ * interleaved per point); out: device fp32 [3][n] unit normals. */
+int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
+                     float *normals, pifu_stream stream);
+
+/* ---- OBJ writer: save_obj_mesh_with_color (mesh_util.py:189-198); host buffers ------------------ */
+int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
+                   const int32_t *faces, int64_t nfaces);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIFUHD_HIP_H */

@@ -1,0 +1,273 @@
+// Context management, weight packing and the host-only entry points of libpifuhd_hip.so.
+#include "pifu_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+
+void pifu_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *pifu_last_error(void) { return g_err; }
+extern "C" int pifu_abi_version(void) { return 1; }
+
+int pifu_ensure(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes) return PIFU_OK;
+    if (b.p) {
+        PIFU_HIP(hipDeviceSynchronize());   // growing: nothing may still be using the old arena
+        PIFU_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) {
+            pifu_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            b.p = nullptr;
+            return PIFU_ERR_NOMEM;
+        }
+        b.bytes = bytes;
+        return PIFU_OK;
+    }
+    b.bytes = want;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
+{
+    PIFU_REQUIRE(out, PIFU_ERR_INVALID, "pifu_ctx_create: null out pointer");
+    int ndev = 0;
+    PIFU_HIP(hipGetDeviceCount(&ndev));
+    PIFU_REQUIRE(device >= 0 && device < ndev, PIFU_ERR_INVALID, "pifu_ctx_create: device %d of %d", device, ndev);
+    PIFU_HIP(hipSetDevice(device));
+    pifu_ctx *c = new pifu_ctx();
+    c->device = device;
+    if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        pifu_set_error("pinned host allocation failed");
+        return PIFU_ERR_HIP;
+    }
+    {
+        std::vector<float> ones(PIFU_MAX_WIDTH, 1.f);
+        if (hipMalloc(&c->ident_scale, PIFU_MAX_WIDTH * sizeof(float)) != hipSuccess ||
+            hipMalloc(&c->ident_shift, PIFU_MAX_WIDTH * sizeof(float)) != hipSuccess ||
+            hipMemcpy(c->ident_scale, ones.data(), PIFU_MAX_WIDTH * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(c->ident_shift, 0, PIFU_MAX_WIDTH * sizeof(float)) != hipSuccess) {
+            pifu_set_error("identity scale/shift allocation failed");
+            pifu_ctx_destroy(c);
+            return PIFU_ERR_HIP;
+        }
+    }
+    *out = c;
+    return PIFU_OK;
+}
+
+static void free_layer(MlpLayer &l)
+{
+    float **ptrs[] = {&l.w, &l.bias, &l.gamma, &l.beta, &l.fixed_scale, &l.fixed_shift};
+    for (float **p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    l.set = false;
+}
+
+extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
+{
+    if (!ctx) return PIFU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int L = 0; L < 2; ++L) {
+        for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(ctx->mlp[L].layer[i]);
+        if (ctx->feat[L].nhwc) (void)hipFree(ctx->feat[L].nhwc);
+    }
+    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
+    if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
+    delete ctx;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_reserve(pifu_ctx *ctx, int64_t rows)
+{
+    PIFU_REQUIRE(ctx && rows > 0, PIFU_ERR_INVALID, "pifu_reserve: bad argument");
+    ctx->ws_rows = round_up(rows, PIFU_BM);
+    return PIFU_OK;
+}
+
+extern "C" int64_t pifu_workspace_bytes(pifu_ctx *ctx)
+{
+    return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes) : 0;
+}
+
+extern "C" int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div)
+{
+    PIFU_REQUIRE(ctx && z_div != 0.f, PIFU_ERR_INVALID, "pifu_set_depth_normalizer: bad argument");
+    ctx->z_mul = z_mul;
+    ctx->z_div = z_div;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, int ndims, const int32_t *res_layers,
+                               int nres, int merge_layer, int norm)
+{
+    PIFU_REQUIRE(ctx && dims, PIFU_ERR_INVALID, "pifu_mlp_define: null argument");
+    PIFU_REQUIRE(level == 0 || level == 1, PIFU_ERR_INVALID, "pifu_mlp_define: level must be 0 or 1");
+    PIFU_REQUIRE(ndims >= 3 && ndims <= PIFU_MAX_LAYERS + 1, PIFU_ERR_INVALID, "pifu_mlp_define: 3 <= len(dims) <= %d", PIFU_MAX_LAYERS + 1);
+    PIFU_REQUIRE(norm >= PIFU_NORM_NONE && norm <= PIFU_NORM_BATCH_TRAIN, PIFU_ERR_INVALID, "pifu_mlp_define: unknown norm %d", norm);
+    PIFU_REQUIRE(dims[ndims - 1] == 1, PIFU_ERR_INVALID, "pifu_mlp_define: the last layer must have one output channel (occupancy)");
+    PIFU_REQUIRE(level == 0 || ctx->mlp[0].defined, PIFU_ERR_STATE, "pifu_mlp_define: define the coarse MLP before the fine one");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    Mlp &m = ctx->mlp[level];
+    for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(m.layer[i]);
+    m = Mlp();
+    m.ndims = ndims;
+    m.nlayers = ndims - 1;
+    for (int i = 0; i < ndims; ++i) {
+        PIFU_REQUIRE(dims[i] > 0 && dims[i] <= PIFU_MAX_WIDTH - PIFU_BN, PIFU_ERR_INVALID, "pifu_mlp_define: dims[%d] = %d", i, dims[i]);
+        m.dims[i] = dims[i];
+    }
+    for (int i = 0; i < nres; ++i) {
+        // a skip-concat at layer 0 would concatenate the input with itself; the reference never does it
+        PIFU_REQUIRE(res_layers[i] >= 1 && res_layers[i] < m.nlayers, PIFU_ERR_INVALID, "pifu_mlp_define: res layer %d out of range", res_layers[i]);
+        m.res[res_layers[i]] = true;
+    }
+    m.merge_layer = merge_layer > 0 ? merge_layer : ndims / 2;          // MLP.py:25
+    PIFU_REQUIRE(m.merge_layer < m.nlayers - 1, PIFU_ERR_INVALID, "pifu_mlp_define: merge_layer %d must be a hidden layer", m.merge_layer);
+    m.norm = norm;
+    if (norm == PIFU_NORM_GROUP)
+        for (int i = 1; i < ndims - 1; ++i)
+            PIFU_REQUIRE(dims[i] % 32 == 0, PIFU_ERR_INVALID, "pifu_mlp_define: GroupNorm(32, %d) is not defined", dims[i]);
+    // input feature split: coarse = [image features | z]; fine = [fine features | phi]
+    int feat_pad;
+    if (level == 0) {
+        feat_pad = (int)round_up(dims[0], PIFU_BK);
+    } else {
+        const Mlp &mc = ctx->mlp[0];
+        const int cphi = mc.dims[mc.merge_layer + 1];
+        PIFU_REQUIRE(dims[0] > cphi, PIFU_ERR_INVALID, "pifu_mlp_define: fine input %d must exceed the coarse phi width %d", dims[0], cphi);
+        feat_pad = (int)round_up(dims[0] - cphi, PIFU_BK) + mc.layer[mc.merge_layer].cout_pad;
+    }
+    for (int i = 0; i < m.nlayers; ++i) {
+        MlpLayer &l = m.layer[i];
+        l.cin_prev = i == 0 ? 0 : dims[i];
+        l.cin_feat = (i == 0 || m.res[i]) ? dims[0] : 0;
+        l.cout = dims[i + 1];
+        l.has_norm = i != m.nlayers - 1;
+        l.cout_pad = l.has_norm ? (int)round_up(l.cout, PIFU_BN) : l.cout;
+        const int prev_pad = i == 0 ? 0 : m.layer[i - 1].cout_pad;
+        l.kpad = prev_pad + (l.cin_feat ? feat_pad : 0);
+    }
+    m.defined = true;
+    return PIFU_OK;
+}
+
+static int upload(float **dst, const std::vector<float> &host)
+{
+    if (*dst) {
+        PIFU_HIP(hipFree(*dst));
+        *dst = nullptr;
+    }
+    PIFU_HIP(hipMalloc(dst, host.size() * sizeof(float)));
+    PIFU_HIP(hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PIFU_OK;
+}
+
+extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight, const float *bias,
+                                  const float *norm_weight, const float *norm_bias, const float *running_mean,
+                                  const float *running_var)
+{
+    PIFU_REQUIRE(ctx && weight && bias, PIFU_ERR_INVALID, "pifu_mlp_set_layer: null argument");
+    PIFU_REQUIRE(level == 0 || level == 1, PIFU_ERR_INVALID, "pifu_mlp_set_layer: level must be 0 or 1");
+    Mlp &m = ctx->mlp[level];
+    PIFU_REQUIRE(m.defined, PIFU_ERR_STATE, "pifu_mlp_set_layer: MLP level %d is not defined", level);
+    PIFU_REQUIRE(layer >= 0 && layer < m.nlayers, PIFU_ERR_INVALID, "pifu_mlp_set_layer: layer %d out of range", layer);
+    PIFU_HIP(hipSetDevice(ctx->device));
+    MlpLayer &l = m.layer[layer];
+    const int cin = l.cin_prev + l.cin_feat;
+    const int prev_pad = layer == 0 ? 0 : m.layer[layer - 1].cout_pad;
+    // column map: reference input channel -> padded K column
+    std::vector<int> colmap(cin);
+    for (int k = 0; k < l.cin_prev; ++k) colmap[k] = k;
+    if (l.cin_feat) {
+        if (level == 0) {
+            for (int k = 0; k < l.cin_feat; ++k) colmap[l.cin_prev + k] = prev_pad + k;
+        } else {
+            const Mlp &mc = ctx->mlp[0];
+            const int cphi = mc.dims[mc.merge_layer + 1];
+            const int cfine = m.dims[0] - cphi;
+            const int fine_pad = (int)round_up(cfine, PIFU_BK);
+            for (int k = 0; k < cfine; ++k) colmap[l.cin_prev + k] = prev_pad + k;
+            for (int k = 0; k < cphi; ++k) colmap[l.cin_prev + cfine + k] = prev_pad + fine_pad + k;
+        }
+    }
+    std::vector<float> w((size_t)(l.cout_pad > 0 ? l.cout_pad : 1) * l.kpad, 0.f);
+    for (int o = 0; o < l.cout; ++o)
+        for (int k = 0; k < cin; ++k) w[(size_t)o * l.kpad + colmap[k]] = weight[(size_t)o * cin + k];
+    int rc = upload(&l.w, w);
+    if (rc) return rc;
+    std::vector<float> b(l.cout_pad > 0 ? l.cout_pad : 1, 0.f);
+    for (int o = 0; o < l.cout; ++o) b[o] = bias[o];
+    if ((rc = upload(&l.bias, b))) return rc;
+    l.host_bias0 = bias[0];
+    if (l.has_norm) {
+        std::vector<float> g(l.cout_pad, 0.f), be(l.cout_pad, 0.f), fs(l.cout_pad, 0.f), fb(l.cout_pad, 0.f);
+        if (m.norm != PIFU_NORM_NONE) {
+            PIFU_REQUIRE(norm_weight && norm_bias, PIFU_ERR_INVALID, "pifu_mlp_set_layer: layer %d needs norm weight/bias", layer);
+            for (int o = 0; o < l.cout; ++o) { g[o] = norm_weight[o]; be[o] = norm_bias[o]; }
+        }
+        if (m.norm == PIFU_NORM_BATCH_EVAL) {
+            PIFU_REQUIRE(running_mean && running_var, PIFU_ERR_INVALID, "pifu_mlp_set_layer: batch-eval needs running statistics");
+            for (int o = 0; o < l.cout; ++o) {
+                const double rstd = 1.0 / sqrt((double)running_var[o] + 1e-5);
+                fs[o] = (float)(norm_weight[o] * rstd);
+                fb[o] = (float)((double)norm_bias[o] - (double)running_mean[o] * rstd * norm_weight[o]);
+            }
+        }
+        if ((rc = upload(&l.gamma, g))) return rc;
+        if ((rc = upload(&l.beta, be))) return rc;
+        if ((rc = upload(&l.fixed_scale, fs))) return rc;
+        if ((rc = upload(&l.fixed_shift, fb))) return rc;
+    }
+    l.set = true;
+    return PIFU_OK;
+}
+
+// save_obj_mesh_with_color (mesh_util.py:189-198): 'v %.4f %.4f %.4f %.4f %.4f %.4f', faces 1-based (f0, f2, f1)
+extern "C" int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
+                              const int32_t *faces, int64_t nfaces)
+{
+    PIFU_REQUIRE(path && (verts || nverts == 0) && (faces || nfaces == 0), PIFU_ERR_INVALID, "pifu_write_obj: null argument");
+    FILE *f = fopen(path, "w");
+    PIFU_REQUIRE(f, PIFU_ERR_INVALID, "pifu_write_obj: cannot open %s", path);
+    std::vector<char> buf(1 << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    for (int64_t i = 0; i < nverts; ++i) {
+        const double *v = verts + 3 * i, *c = colors + 3 * i;
+        fprintf(f, "v %.4f %.4f %.4f %.4f %.4f %.4f\n", v[0], v[1], v[2], c[0], c[1], c[2]);
+    }
+    for (int64_t i = 0; i < nfaces; ++i) {
+        const int32_t *t = faces + 3 * i;
+        fprintf(f, "f %d %d %d\n", t[0] + 1, t[2] + 1, t[1] + 1);
+    }
+    const bool bad = ferror(f);
+    fclose(f);
+    PIFU_REQUIRE(!bad, PIFU_ERR_INVALID, "pifu_write_obj: write error on %s", path);
+    return PIFU_OK;
+}

@@ -1,0 +1,109 @@
+// Internal declarations shared by the translation units of libpifuhd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pifuhd_hip.h"
+
+void pifu_set_error(const char *fmt, ...);
+
+#define PIFU_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            pifu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
+                           __LINE__);                                                        \
+            return PIFU_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define PIFU_REQUIRE(cond, code, ...)   \
+    do {                                \
+        if (!(cond)) {                  \
+            pifu_set_error(__VA_ARGS__);\
+            return (code);              \
+        }                               \
+    } while (0)
+
+// GEMM tile geometry of the MLP layers (see DESIGN.md "mlp_gemm")
+constexpr int PIFU_BM = 128;   // points per block tile (also the padding quantum of a chunk)
+constexpr int PIFU_BN = 128;   // output channels per block tile
+constexpr int PIFU_BK = 32;    // K step; every K segment is padded to a multiple of it
+constexpr int PIFU_MAX_LAYERS = 8;
+constexpr int PIFU_MAX_WIDTH = 8192;  // widest MLP layer / input supported
+
+static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct MlpLayer {
+    int cin_prev = 0;      // channels coming from the previous layer (0 for layer 0)
+    int cin_feat = 0;      // channels of the skip-concatenated MLP input (0 if not a res layer / layer 0: all)
+    int cout = 0, cout_pad = 0;
+    int kpad = 0;          // padded K = sum of padded segment widths
+    bool has_norm = false; // followed by norm + leaky (all but the last layer)
+    float *w = nullptr;    // device [cout_pad][kpad]
+    float *bias = nullptr; // device [cout_pad]
+    float *gamma = nullptr, *beta = nullptr;       // device [cout_pad] (affine of the norm)
+    float *fixed_scale = nullptr, *fixed_shift = nullptr;  // device [cout_pad] for NONE / BATCH_EVAL
+    float host_bias0 = 0.f; // bias of a 1-channel (last) layer, kept on the host
+    bool set = false;
+};
+
+struct Mlp {
+    bool defined = false;
+    int ndims = 0;
+    int dims[PIFU_MAX_LAYERS + 1] = {0};
+    bool res[PIFU_MAX_LAYERS] = {false};
+    int merge_layer = 0;
+    int norm = PIFU_NORM_GROUP;
+    int nlayers = 0;
+    MlpLayer layer[PIFU_MAX_LAYERS];
+};
+
+struct FeatMap {
+    float *nhwc = nullptr;  // device [H][W][Cpad]
+    int C = 0, Cpad = 0, H = 0, W = 0;
+    size_t bytes = 0;
+};
+
+struct McState {
+    bool valid = false;
+    int n0 = 0, n1 = 0, n2 = 0;
+    double level = 0;
+    int dtype = 0;
+    const void *volume = nullptr;
+    int64_t nverts = 0, nfaces = 0;
+};
+
+struct pifu_ctx {
+    int device = 0;
+    Mlp mlp[2];
+    FeatMap feat[2];
+    float z_mul = 512.f, z_div = 200.f;
+    // query workspace (grown lazily; everything lives in one arena)
+    DevBuf arena;
+    int64_t ws_rows = 0;
+    // marching-cubes workspace
+    DevBuf mc_arena;
+    McState mc;
+    // octree scratch
+    DevBuf oct_arena;
+    // small persistent device scratch (scan totals etc.)
+    DevBuf misc;
+    void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
+    float *ident_scale = nullptr, *ident_shift = nullptr;   // device ones / zeros [PIFU_MAX_WIDTH]
+};
+
+int pifu_ensure(DevBuf &b, size_t bytes);   // grow-only hipMalloc (synchronises when it grows)
+
+// implemented in query.hip
+int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n, const int32_t *res,
+                    const double *calib_inv, const int64_t *index, int64_t first, const float *calib,
+                    int64_t chunk, int flags, float *pred_fine, float *pred_coarse, float *phi,
+                    float delta_for_normals, float **normal_pred_out, hipStream_t stream);

@@ -1,0 +1,805 @@
+// Occupancy query for gfx950: projection + bilinear feature sampling + SurfaceClassifier MLPs.
+//
+// Replaces PIFuMRNet.query / PIFuNetwNML.query (PIFuMRNet.py:119-186, PIFuNetwNML.py:99-141),
+// index()/orthogonal() (BasePIFuNet.py:11-43), DepthNormalizer (DepthNormalizer.py:17-24) and
+// MLP.forward (MLP.py:43-75).
+//
+// Data layout (all fp32, point-major so that the K axis of every GEMM is contiguous):
+//   featc [rows][K0c]   coarse MLP input  = [image features | z | 0-pad]      (K0c = roundup(257,32))
+//   finef [rows][32]    fine-level sampled features (16) zero-padded to one K step
+//   Y_l   [rows][Cout]  RAW (pre-norm) conv output of every MLP layer; GroupNorm + LeakyReLU are applied
+//                       by the CONSUMER while it stages the tile (x*scale[chunk][c] + shift[chunk][c]),
+//                       because the statistics span the whole chunk (SURVEY C-1) and are only known
+//                       after the producing GEMM has finished.
+//   rows: every reference-side query() call ("chunk") is padded to a multiple of 128 rows, so a GEMM
+//   row tile never straddles two chunks; padded rows carry zero features and are masked out of the
+//   statistics.
+//
+// The dominant kernel is k_mlp_gemm: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), 128x128x32 block tile,
+// 4 waves each owning a 64x64 output tile (2x2 MFMA tiles, 64 accumulator VGPRs), register-staged
+// double-buffered LDS with the norm+LeakyReLU prologue fused into the staging pass, per-column
+// (sum, sum^2) partials for the next norm fused into the epilogue (deterministic: no atomics).
+#include "pifu_internal.h"
+
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = PIFU_BM, BN = PIFU_BN, BK = PIFU_BK;
+constexpr int LDS_LD = BK + 4;           // 36 floats = 144 B row stride: conflict-free ds_read_b128
+constexpr int TILE_FLOATS = BM * LDS_LD; // one operand tile in LDS
+
+struct Seg {
+    const float *ptr;     // [rows][ld]
+    const float *scale;   // [nchunks][sld]; modes 0 and 2 point at a constant ones / zeros row (sld 0)
+    const float *shift;
+    int ld;
+    int width;            // multiple of BK
+    int sld;              // stride between chunks of scale/shift (0 = shared by all chunks)
+    int mode;             // 0 raw, 1 affine + LeakyReLU(0.01), 2 LeakyReLU only
+};
+
+struct ChunkGeom {
+    int tpc;       // row tiles per chunk (P = tpc * BM rows per chunk)
+    int chunk;     // points in a full chunk
+    int last_len;  // points in the last chunk of this batch
+    int nchunks;   // chunks in this batch
+};
+
+struct GemmArgs {
+    Seg seg[3];
+    int nseg;
+    const float *W;   // [cout_pad][ldw]
+    int ldw;          // = padded K
+    const float *bias;
+    float *Y;         // [rows][ldy]
+    int ldy;
+    float2 *partial;  // [ntm][ldy] (sum, sum of squares) over the valid rows of the tile, or null
+    int ntm, ntn;
+    ChunkGeom g;
+};
+
+__device__ __forceinline__ int chunk_len(const ChunkGeom &g, int c) { return c == g.nchunks - 1 ? g.last_len : g.chunk; }
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
+
+// ------------------------------------------------------------------------------------------------
+// k_mlp_gemm:  Y[rows][Cout] = act(A)[rows][K] * W^T + bias,  A = concatenation of <= 3 segments.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // [buf][A|B] = 73,728 B
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so all column tiles of
+    // one row tile get the same (b % 8) label and consecutive slots -> the A row tile is re-read from that
+    // XCD's L2, not from HBM.  Pure speed choice; correctness does not depend on placement.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM;
+    const int col0 = tile_n * BN;
+
+    const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
+    const int b1 = a.seg[0].width;
+    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
+    const int nsteps = a.ldw / BK;
+
+    // One K step of both operands in flight in registers (issued before the MFMAs of the current step,
+    // transformed and written to the other LDS buffer after them).  The per-segment choices are selected
+    // with scalar selects so the staging code is branch-free: raw segments use scale 1 / shift 0 / slope 1.
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
+    float rslope = 1.f;
+
+#define PIFU_GLOAD(step_)                                                                                  \
+    {                                                                                                      \
+        const int kk = (step_) * BK;                                                                       \
+        const int sg = (kk >= b1) + (kk >= b2);                                                            \
+        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
+        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
+        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
+        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
+        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
+        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
+        rslope = md == 0 ? 1.f : 0.01f;                                                                    \
+        const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
+        const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
+        ra0 = *reinterpret_cast<const float4 *>(ap);                                                       \
+        ra1 = *reinterpret_cast<const float4 *>(ap + (size_t)32 * ld);                                     \
+        ra2 = *reinterpret_cast<const float4 *>(ap + (size_t)64 * ld);                                     \
+        ra3 = *reinterpret_cast<const float4 *>(ap + (size_t)96 * ld);                                     \
+        rsc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                         \
+        rsh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                         \
+        const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                                 \
+        rw0 = *reinterpret_cast<const float4 *>(wp);                                                       \
+        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)32 * a.ldw);                                  \
+        rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)64 * a.ldw);                                  \
+        rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)96 * a.ldw);                                  \
+    }
+
+#define PIFU_XFORM(v_)                                                                                     \
+    {                                                                                                      \
+        float t_;                                                                                          \
+        t_ = fmaf(v_.x, rsc.x, rsh.x); v_.x = fmaxf(t_, rslope * t_);                                      \
+        t_ = fmaf(v_.y, rsc.y, rsh.y); v_.y = fmaxf(t_, rslope * t_);                                      \
+        t_ = fmaf(v_.z, rsc.z, rsh.z); v_.z = fmaxf(t_, rslope * t_);                                      \
+        t_ = fmaf(v_.w, rsc.w, rsh.w); v_.w = fmaxf(t_, rslope * t_);                                      \
+    }
+
+#define PIFU_LSTORE(buf_)                                                                                  \
+    {                                                                                                      \
+        float *la = lds + (buf_) * 2 * TILE_FLOATS + sr * LDS_LD + kq * 4;                                 \
+        float *lb = la + TILE_FLOATS;                                                                      \
+        PIFU_XFORM(ra0) PIFU_XFORM(ra1) PIFU_XFORM(ra2) PIFU_XFORM(ra3)                                    \
+        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
+        *reinterpret_cast<float4 *>(la + 32 * LDS_LD) = ra1;                                               \
+        *reinterpret_cast<float4 *>(la + 64 * LDS_LD) = ra2;                                               \
+        *reinterpret_cast<float4 *>(la + 96 * LDS_LD) = ra3;                                               \
+        *reinterpret_cast<float4 *>(lb) = rw0;                                                             \
+        *reinterpret_cast<float4 *>(lb + 32 * LDS_LD) = rw1;                                               \
+        *reinterpret_cast<float4 *>(lb + 64 * LDS_LD) = rw2;                                               \
+        *reinterpret_cast<float4 *>(lb + 96 * LDS_LD) = rw3;                                               \
+    }
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    PIFU_GLOAD(0)
+    PIFU_LSTORE(0)
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) PIFU_GLOAD(step + 1)
+
+        // lane (i = lane & 31, h = lane >> 5) reads k = 8 s + 4 h + t, t = 0..3, for both operands
+        const float *A = lds + buf * 2 * TILE_FLOATS + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+        const float *B = lds + buf * 2 * TILE_FLOATS + TILE_FLOATS + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LDS_LD + s * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
+            const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LDS_LD + s * 8);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+            }
+        }
+        if (more) PIFU_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
+    const int h = lane >> 5, j = lane & 31;
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = col0 + wn * 64 + nt * 32 + j;
+        const float bias = a.bias[col];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[r] + bias;
+                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
+                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
+            }
+        }
+        if (a.partial) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (lane < 32) {
+                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
+                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
+            }
+        }
+    }
+    if (a.partial) {
+        __syncthreads();
+        if (tid < BN)
+            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_norm_finalize: (sum, sum^2) partials -> per-(chunk, channel) scale/shift of the following norm.
+// One wave per (chunk, group); double accumulation in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int groups, const float *gamma,
+                                const float *beta, float *scale, float *shift, ChunkGeom g, float eps)
+{
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= g.nchunks * groups) return;
+    const int c = wid / groups, grp = wid % groups;
+    const int len = chunk_len(g, c);
+    const int ntile = (len + BM - 1) / BM;
+    double s = 0.0, q = 0.0;
+    const int total = ntile * cpg;
+    for (int i = lane; i < total; i += 64) {
+        const int t = i / cpg, ch = grp * cpg + i % cpg;
+        const float2 p = partial[(size_t)(c * g.tpc + t) * ld + ch];
+        s += (double)p.x;
+        q += (double)p.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    const double cnt = (double)len * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int i = lane; i < cpg; i += 64) {
+        const int ch = grp * cpg + i;
+        const double gm = gamma[ch];
+        scale[(size_t)c * ld + ch] = (float)(gm * rstd);
+        shift[(size_t)c * ld + ch] = (float)((double)beta[ch] - mean * rstd * gm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_last_layer: the Cout = 1 layer + sigmoid + bounding-box mask.  16 lanes per point row.
+// ------------------------------------------------------------------------------------------------
+struct LastArgs {
+    Seg seg[3];
+    int nseg;
+    const float *w;          // [kpad]
+    float bias;
+    const uint8_t *mask;     // per row; bit0 = coarse in_bb (x,y,z), bit1 = fine in_bb (x,y)
+    int mask_bit;            // 1, 2 or 0 (no mask)
+    float *out;              // [points of this batch], indexed c * chunk + local
+    int64_t rows;
+    ChunkGeom g;
+};
+
+__global__ void k_last_layer(const LastArgs a)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (row >= a.rows) return;
+    const int P = a.g.tpc * BM;
+    const int c = (int)(row / P), local = (int)(row % P);
+    const bool valid = local < chunk_len(a.g, c);
+    float dot = 0.f;
+    int kbase = 0;
+    for (int sg = 0; sg < a.nseg; ++sg) {
+        const Seg &S = a.seg[sg];
+        const float *x = S.ptr + (size_t)row * S.ld;
+        for (int k = sub * 4; k < S.width; k += 64) {
+            float4 v = *reinterpret_cast<const float4 *>(x + k);
+            if (S.mode == 1) {
+                const float4 sc = *reinterpret_cast<const float4 *>(S.scale + (size_t)c * S.sld + k);
+                const float4 sh = *reinterpret_cast<const float4 *>(S.shift + (size_t)c * S.sld + k);
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            }
+            if (S.mode != 0) { v.x = leaky(v.x); v.y = leaky(v.y); v.z = leaky(v.z); v.w = leaky(v.w); }
+            const float4 w = *reinterpret_cast<const float4 *>(a.w + kbase + k);
+            dot = fmaf(v.x, w.x, dot); dot = fmaf(v.y, w.y, dot);
+            dot = fmaf(v.z, w.z, dot); dot = fmaf(v.w, w.w, dot);
+        }
+        kbase += S.width;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (sub == 0 && valid) {
+        float p = 1.f / (1.f + expf(-(dot + a.bias)));
+        if (a.mask_bit && !(a.mask[row] & a.mask_bit)) p = 0.f;     // pred * in_bb
+        a.out[(int64_t)c * a.g.chunk + local] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sample: project -> in-bbox masks -> bilinear taps (NHWC feature maps) -> MLP input rows.
+// One wave per point row; one tap = one contiguous channel row, 16 B per lane.
+// ------------------------------------------------------------------------------------------------
+struct SrcDesc {
+    int mode;                 // 0 explicit points [3][n]; 1 lattice (flat = first + i); 2 lattice (flat = index[first + i]);
+                              // 3 calc_normal (points [3][n/4] perturbed by delta)
+    const float *pts;
+    int64_t pts_n;            // n of the [3][n] array
+    int res[3];
+    double cinv[12];          // rows of calib^-1 (3x4)
+    const int64_t *index;
+    int64_t first;            // first point of this batch
+    float delta;
+};
+
+struct SampleArgs {
+    SrcDesc src;
+    float calib[12];          // 3x4 rows of the (local == global) calibration
+    const float *fc; int Cc, Ccp, Hc, Wc;     // coarse NHWC map
+    const float *ff; int Cf, Cfp, Hf, Wf;     // fine NHWC map (null if coarse only)
+    float z_mul, z_div;
+    float *featc; int ldc;
+    float *finef; int ldf;
+    uint8_t *mask;
+    int64_t rows;
+    ChunkGeom g;
+};
+
+__device__ __forceinline__ void bilinear_setup(float u, float v, int W, int H, int (&off)[4], float (&wt)[4])
+{
+    // grid_sample(align_corners=True, padding zeros) as used by index() (BasePIFuNet.py:22)
+    const float ix = ((u + 1.f) * 0.5f) * (float)(W - 1);
+    const float iy = ((v + 1.f) * 0.5f) * (float)(H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wts[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};   // nw, ne, sw, se
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int x = x0 + (t & 1), y = y0 + (t >> 1);
+        const bool ok = x >= 0 && x < W && y >= 0 && y < H;
+        off[t] = ok ? (y * W + x) : -1;
+        wt[t] = wts[t];
+    }
+}
+
+__global__ void k_sample(const SampleArgs a)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= a.rows) return;
+    const int P = a.g.tpc * BM;
+    const int c = (int)(row / P), local = (int)(row % P);
+    const bool valid = local < chunk_len(a.g, c);
+    float *fc_out = a.featc + (size_t)row * a.ldc;
+    float *ff_out = a.finef ? a.finef + (size_t)row * a.ldf : nullptr;
+    if (!valid) {   // padded row: zero features keep every downstream value finite; excluded from statistics
+        for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
+        if (ff_out && lane * 4 < a.ldf) *reinterpret_cast<float4 *>(ff_out + lane * 4) = make_float4(0, 0, 0, 0);
+        if (lane == 0) a.mask[row] = 0;
+        return;
+    }
+    const int64_t i = a.src.first + (int64_t)c * a.g.chunk + local;   // point index within the call
+    float px, py, pz;
+    if (a.src.mode == 0) {
+        px = a.src.pts[i]; py = a.src.pts[a.src.pts_n + i]; pz = a.src.pts[2 * a.src.pts_n + i];
+    } else if (a.src.mode == 3) {
+        const int64_t vtx = i >> 2;
+        const int axis = (int)(i & 3) - 1;
+        px = a.src.pts[vtx]; py = a.src.pts[a.src.pts_n + vtx]; pz = a.src.pts[2 * a.src.pts_n + vtx];
+        if (axis == 0) px += a.src.delta;
+        if (axis == 1) py += a.src.delta;
+        if (axis == 2) pz += a.src.delta;
+    } else {
+        const int64_t flat = a.src.mode == 1 ? i : a.src.index[i];
+        const int64_t r12 = (int64_t)a.src.res[1] * a.src.res[2];
+        const int gi = (int)(flat / r12), gj = (int)((flat / a.src.res[2]) % a.src.res[1]), gk = (int)(flat % a.src.res[2]);
+        // create_grid (mesh_util.py:28-33): coords = idx * (2/res) + (-1), separate multiply and add in float64
+        const double gx = __dadd_rn(__dmul_rn((double)gi, 2.0 / a.src.res[0]), -1.0);
+        const double gy = __dadd_rn(__dmul_rn((double)gj, 2.0 / a.src.res[1]), -1.0);
+        const double gz = __dadd_rn(__dmul_rn((double)gk, 2.0 / a.src.res[2]), -1.0);
+        const double *m = a.src.cinv;   // [g,1] . calib_inv^T (mesh_util.py:64), then .float() (mesh_util.py:70)
+        px = (float)(gx * m[0] + gy * m[1] + gz * m[2] + m[3]);
+        py = (float)(gx * m[4] + gy * m[5] + gz * m[6] + m[7]);
+        pz = (float)(gx * m[8] + gy * m[9] + gz * m[10] + m[11]);
+    }
+    // orthogonal(): xyz = R p + t (BasePIFuNet.py:25-43)
+    const float *k = a.calib;
+    const float x = fmaf(k[2], pz, fmaf(k[1], py, fmaf(k[0], px, k[3])));
+    const float y = fmaf(k[6], pz, fmaf(k[5], py, fmaf(k[4], px, k[7])));
+    const float z = fmaf(k[10], pz, fmaf(k[9], py, fmaf(k[8], px, k[11])));
+    const bool in_xy = x >= -1.f && x <= 1.f && y >= -1.f && y <= 1.f;
+    const bool in_xyz = in_xy && z >= -1.f && z <= 1.f;
+    if (lane == 0) a.mask[row] = (uint8_t)((in_xyz ? 1 : 0) | (in_xy ? 2 : 0));
+
+    int off[4];
+    float wt[4];
+    bilinear_setup(x, y, a.Wc, a.Hc, off, wt);
+    for (int ch = lane * 4; ch < a.Ccp; ch += 256) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (off[t] >= 0) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.fc + (size_t)off[t] * a.Ccp + ch);
+                acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
+                acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
+            }
+        }
+        *reinterpret_cast<float4 *>(fc_out + ch) = acc;
+    }
+    // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
+    for (int col = a.Cc + lane; col < a.ldc; col += 64)
+        fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
+
+    if (ff_out) {
+        bilinear_setup(x, y, a.Wf, a.Hf, off, wt);
+        for (int ch = lane * 4; ch < a.ldf; ch += 256) {
+            float4 acc = make_float4(0, 0, 0, 0);
+            if (ch < a.Cfp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (off[t] >= 0) {
+                        const float4 v = *reinterpret_cast<const float4 *>(a.ff + (size_t)off[t] * a.Cfp + ch);
+                        acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
+                        acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
+                    }
+                }
+            }
+            *reinterpret_cast<float4 *>(ff_out + ch) = acc;
+        }
+    }
+}
+
+// NCHW -> NHWC (channel-padded) repack of a feature map, once per image.
+__global__ void k_nchw_to_nhwc(const float *src, float *dst, int C, int Cp, int HW)
+{
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < Cp) dst[(size_t)p * Cp + c] = tile[tx][r];
+    }
+}
+
+// phi export: [C][n] = leaky(Y[n][C] * scale + shift)  (netG.phi, PIFuNetwNML.py:137-138)
+__global__ void k_phi_export(const float *Y, int ld, const float *scale, const float *shift, int mode, int C,
+                             int64_t n, float *out)
+{
+    __shared__ float tile[32][33];
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t p = p0 + r;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (p < n && c < C) {
+            v = Y[(size_t)p * ld + c];
+            if (mode == 1) v = fmaf(v, scale[c], shift[c]);
+            if (mode != 0) v = leaky(v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const int64_t p = p0 + tx;
+        if (c < C && p < n) out[(size_t)c * n + p] = tile[tx][r];
+    }
+}
+
+// calc_normal tail: pred [4n] interleaved -> unit normals [3][n]  (PIFuMRNet.py:232-239)
+__global__ void k_normals(const float *pred, int64_t n, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 f = *reinterpret_cast<const float4 *>(pred + 4 * i);
+    const float nx = -(f.y - f.x), ny = -(f.z - f.x), nz = -(f.w - f.x);
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float d = fmaxf(len, 1e-8f);                       // F.normalize(dim=1, eps=1e-8)
+    out[i] = nx / d; out[n + i] = ny / d; out[2 * n + i] = nz / d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct LevelBufs {
+    float *out[PIFU_MAX_LAYERS] = {nullptr};     // raw layer outputs [rows][cout_pad]
+    float2 *partial[PIFU_MAX_LAYERS] = {nullptr};
+    float *scale[PIFU_MAX_LAYERS] = {nullptr};   // [nchunks][cout_pad]
+    float *shift[PIFU_MAX_LAYERS] = {nullptr};
+};
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t count)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct Plan {
+    float *featc; int ldc;
+    float *finef; int ldf;
+    uint8_t *mask;
+    float *normal_pred;
+    float *coarse_scratch;
+    LevelBufs lv[2];
+    size_t bytes;
+};
+
+Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fine, int64_t normal_pts)
+{
+    Plan p;
+    Carver c{base};
+    const Mlp &mc = ctx->mlp[0];
+    p.ldc = (int)round_up(mc.dims[0], BK);
+    p.featc = c.take<float>((size_t)rows * p.ldc);
+    p.ldf = fine ? (int)round_up(ctx->feat[1].C > 0 ? ctx->feat[1].C : 16, BK) : 0;
+    p.finef = fine ? c.take<float>((size_t)rows * p.ldf) : nullptr;
+    p.mask = c.take<uint8_t>((size_t)rows);
+    p.normal_pred = normal_pts ? c.take<float>((size_t)normal_pts) : nullptr;
+    p.coarse_scratch = c.take<float>((size_t)rows);
+    const int64_t ntm = rows / BM;
+    for (int L = 0; L < (fine ? 2 : 1); ++L) {
+        const Mlp &m = ctx->mlp[L];
+        for (int i = 0; i < m.nlayers - 1; ++i) {
+            const int cp = m.layer[i].cout_pad;
+            p.lv[L].out[i] = c.take<float>((size_t)rows * cp);
+            p.lv[L].partial[i] = c.take<float2>((size_t)ntm * cp);
+            p.lv[L].scale[i] = c.take<float>((size_t)max_chunks * cp);
+            p.lv[L].shift[i] = c.take<float>((size_t)max_chunks * cp);
+        }
+    }
+    p.bytes = c.off + 256;
+    return p;
+}
+
+Seg make_prev_seg(const pifu_ctx *ctx, const Mlp &m, const LevelBufs &b, int layer_of_output)
+{
+    const MlpLayer &l = m.layer[layer_of_output];
+    Seg s{};
+    s.ptr = b.out[layer_of_output];
+    s.ld = l.cout_pad;
+    s.width = l.cout_pad;
+    if (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN) {
+        s.scale = b.scale[layer_of_output];
+        s.shift = b.shift[layer_of_output];
+        s.sld = l.cout_pad;
+        s.mode = 1;
+    } else if (m.norm == PIFU_NORM_BATCH_EVAL) {
+        s.scale = l.fixed_scale;
+        s.shift = l.fixed_shift;
+        s.sld = 0;
+        s.mode = 1;
+    } else {
+        s.scale = ctx->ident_scale;
+        s.shift = ctx->ident_shift;
+        s.sld = 0;
+        s.mode = 2;
+    }
+    return s;
+}
+
+}  // namespace
+
+int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, int H, int W, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && feat_nchw, PIFU_ERR_INVALID, "pifu_set_features: null argument");
+    PIFU_REQUIRE(level == 0 || level == 1, PIFU_ERR_INVALID, "pifu_set_features: level must be 0 or 1");
+    PIFU_REQUIRE(C > 0 && C % 4 == 0 && H > 1 && W > 1, PIFU_ERR_INVALID,
+                 "pifu_set_features: need C %% 4 == 0 and H, W > 1 (got C=%d H=%d W=%d)", C, H, W);
+    PIFU_HIP(hipSetDevice(ctx->device));
+    FeatMap &f = ctx->feat[level];
+    const size_t bytes = (size_t)H * W * C * sizeof(float);
+    if (bytes > f.bytes) {
+        if (f.nhwc) PIFU_HIP(hipFree(f.nhwc));
+        f.nhwc = nullptr;
+        PIFU_HIP(hipMalloc(&f.nhwc, bytes));
+        f.bytes = bytes;
+    }
+    f.C = C; f.Cpad = C; f.H = H; f.W = W;
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, feat_nchw, f.nhwc, C, C, H * W);
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g, int64_t rows, const uint8_t *mask,
+                        int mask_bit, float *pred_out, int upto_layer /* exclusive; nlayers for all */, hipStream_t st)
+{
+    const Mlp &m = ctx->mlp[L];
+    const LevelBufs &b = pl.lv[L];
+    const Mlp &mc = ctx->mlp[0];
+    const int ntm = (int)(rows / BM);
+    // the skip-concatenated MLP input ("feature" in MLP.forward)
+    Seg feat[2];
+    int nfeat = 0;
+    if (L == 0) {
+        feat[0] = Seg{pl.featc, ctx->ident_scale, ctx->ident_shift, pl.ldc, pl.ldc, 0, 0};
+        nfeat = 1;
+    } else {
+        feat[0] = Seg{pl.finef, ctx->ident_scale, ctx->ident_shift, pl.ldf, pl.ldf, 0, 0};
+        feat[1] = make_prev_seg(ctx, mc, pl.lv[0], mc.merge_layer);      // phi = act(norm(coarse layer merge))
+        nfeat = 2;
+    }
+    for (int i = 0; i < m.nlayers && i < upto_layer; ++i) {
+        const MlpLayer &l = m.layer[i];
+        Seg segs[3];
+        int ns = 0;
+        if (i > 0) segs[ns++] = make_prev_seg(ctx, m, b, i - 1);
+        if (i == 0 || m.res[i])
+            for (int f = 0; f < nfeat; ++f) segs[ns++] = feat[f];
+        int ksum = 0;
+        for (int s = 0; s < ns; ++s) ksum += segs[s].width;
+        PIFU_REQUIRE(ksum == l.kpad, PIFU_ERR_STATE, "internal: K mismatch at level %d layer %d (%d vs %d)", L, i, ksum, l.kpad);
+        if (i < m.nlayers - 1) {
+            GemmArgs a{};
+            for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
+            a.nseg = ns;
+            a.W = l.w; a.ldw = l.kpad; a.bias = l.bias;
+            a.Y = b.out[i]; a.ldy = l.cout_pad;
+            const bool stats = (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN);
+            a.partial = stats ? b.partial[i] : nullptr;
+            a.ntm = ntm; a.ntn = l.cout_pad / BN; a.g = g;
+            const int nblocks = (int)round_up(ntm, 8) * a.ntn;
+            hipLaunchKernelGGL(k_mlp_gemm, dim3(nblocks), dim3(256), 0, st, a);
+            if (stats) {
+                const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
+                const int cpg = l.cout / groups;
+                const int nw = g.nchunks * groups;
+                hipLaunchKernelGGL(k_norm_finalize, dim3((nw + 3) / 4), dim3(256), 0, st, (const float2 *)b.partial[i],
+                                   l.cout_pad, cpg, groups, (const float *)l.gamma, (const float *)l.beta, b.scale[i],
+                                   b.shift[i], g, 1e-5f);
+            }
+        } else {
+            if (!pred_out) continue;
+            LastArgs a{};
+            for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
+            a.nseg = ns;
+            a.w = l.w; a.bias = l.host_bias0; a.mask = mask; a.mask_bit = mask_bit; a.out = pred_out; a.rows = rows; a.g = g;
+            hipLaunchKernelGGL(k_last_layer, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+        }
+    }
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n, const int32_t *res,
+                    const double *calib_inv, const int64_t *index, int64_t first, const float *calib,
+                    int64_t chunk, int flags, float *pred_fine, float *pred_coarse, float *phi,
+                    float delta, float **normal_pred_out, hipStream_t st)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "null context");
+    PIFU_REQUIRE(n >= 0 && chunk > 0, PIFU_ERR_INVALID, "query: need n >= 0 and chunk > 0");
+    if (n == 0) return PIFU_OK;
+    const bool coarse_only = flags & PIFU_Q_COARSE_ONLY;
+    const bool fine = !coarse_only;
+    PIFU_REQUIRE(ctx->mlp[0].defined && ctx->feat[0].nhwc, PIFU_ERR_STATE,
+                 "query before the coarse MLP / feature map were set (filter must precede query)");
+    PIFU_REQUIRE(!fine || (ctx->mlp[1].defined && ctx->feat[1].nhwc), PIFU_ERR_STATE,
+                 "fine-level query before the fine MLP / feature map were set");
+    for (int L = 0; L < (fine ? 2 : 1); ++L)
+        for (int i = 0; i < ctx->mlp[L].nlayers; ++i)
+            PIFU_REQUIRE(ctx->mlp[L].layer[i].set, PIFU_ERR_STATE, "MLP level %d layer %d has no weights", L, i);
+    const Mlp &mc = ctx->mlp[0];
+    PIFU_REQUIRE(ctx->feat[0].C + 1 == mc.dims[0], PIFU_ERR_INVALID,
+                 "coarse MLP expects %d inputs but the feature map has %d channels (+1 depth)", mc.dims[0], ctx->feat[0].C);
+    if (fine)
+        PIFU_REQUIRE(ctx->feat[1].C + mc.dims[mc.merge_layer + 1] == ctx->mlp[1].dims[0], PIFU_ERR_INVALID,
+                     "fine MLP expects %d inputs but fine features (%d) + phi (%d) differ", ctx->mlp[1].dims[0],
+                     ctx->feat[1].C, mc.dims[mc.merge_layer + 1]);
+    PIFU_HIP(hipSetDevice(ctx->device));
+
+    const int64_t eff_chunk = chunk < n ? chunk : n;
+    const int64_t P = round_up(eff_chunk, BM);
+    PIFU_REQUIRE(P <= (int64_t)1 << 30, PIFU_ERR_NOMEM, "chunk of %lld points is too large", (long long)eff_chunk);
+    const int64_t total_chunks = (n + chunk - 1) / chunk;
+    int64_t target_rows = ctx->ws_rows > 0 ? ctx->ws_rows : 262144;
+    int64_t batch_chunks = target_rows / P;
+    if (batch_chunks < 1) batch_chunks = 1;
+    if (batch_chunks > total_chunks) batch_chunks = total_chunks;
+    const int64_t rows_cap = batch_chunks * P;
+    const int64_t normal_pts = src_mode == 3 ? n : 0;
+    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts);
+    int rc = pifu_ensure(ctx->arena, probe.bytes);
+    if (rc != PIFU_OK) return rc;
+    Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts);
+
+    float *fine_out = pred_fine;
+    if (src_mode == 3) {   // calc_normal consumes the predictions itself
+        fine_out = pl.normal_pred;
+        if (normal_pred_out) *normal_pred_out = pl.normal_pred;
+    }
+    if ((flags & PIFU_Q_FULL_COARSE) && !pred_coarse) pred_coarse = pl.coarse_scratch;
+
+    for (int64_t c0 = 0; c0 < total_chunks; c0 += batch_chunks) {
+        const int64_t nc = (total_chunks - c0) < batch_chunks ? (total_chunks - c0) : batch_chunks;
+        const int64_t pt0 = c0 * chunk;
+        const int64_t npts = (pt0 + nc * chunk <= n) ? nc * chunk : (n - pt0);
+        ChunkGeom g;
+        g.tpc = (int)(P / BM);
+        g.chunk = (int)chunk;
+        g.nchunks = (int)nc;
+        g.last_len = (int)(npts - (nc - 1) * chunk);
+        const int64_t rows = nc * P;
+
+        SampleArgs sa{};
+        sa.src.mode = src_mode;
+        sa.src.pts = points;
+        sa.src.pts_n = src_mode == 3 ? n / 4 : n;
+        if (res) { sa.src.res[0] = res[0]; sa.src.res[1] = res[1]; sa.src.res[2] = res[2]; }
+        if (calib_inv) for (int k = 0; k < 12; ++k) sa.src.cinv[k] = calib_inv[k];
+        sa.src.index = index;
+        sa.src.first = first + pt0;
+        sa.src.delta = delta;
+        for (int k = 0; k < 12; ++k) sa.calib[k] = calib[k];
+        sa.fc = ctx->feat[0].nhwc; sa.Cc = ctx->feat[0].C; sa.Ccp = ctx->feat[0].Cpad; sa.Hc = ctx->feat[0].H; sa.Wc = ctx->feat[0].W;
+        if (fine) { sa.ff = ctx->feat[1].nhwc; sa.Cf = ctx->feat[1].C; sa.Cfp = ctx->feat[1].Cpad; sa.Hf = ctx->feat[1].H; sa.Wf = ctx->feat[1].W; }
+        sa.z_mul = ctx->z_mul; sa.z_div = ctx->z_div;
+        sa.featc = pl.featc; sa.ldc = pl.ldc; sa.finef = pl.finef; sa.ldf = pl.ldf; sa.mask = pl.mask;
+        sa.rows = rows; sa.g = g;
+        // the chunk geometry indexes points relative to the batch start: src.first already points there
+        hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
+
+        // coarse level: all layers when netG.preds is wanted, else only up to the merge layer (phi)
+        const bool want_coarse_pred = pred_coarse != nullptr;
+        const int upto = want_coarse_pred ? mc.nlayers : mc.merge_layer + 1;
+        rc = launch_level(ctx, 0, pl, g, rows, pl.mask, 1,
+                          want_coarse_pred ? (pred_coarse == pl.coarse_scratch ? pred_coarse : pred_coarse + pt0) : nullptr, upto, st);
+        if (rc != PIFU_OK) return rc;
+        if (phi && total_chunks == 1) {
+            const MlpLayer &lm = mc.layer[mc.merge_layer];
+            Seg s = make_prev_seg(ctx, mc, pl.lv[0], mc.merge_layer);
+            dim3 grid((unsigned)((npts + 31) / 32), (lm.cout + 31) / 32);
+            hipLaunchKernelGGL(k_phi_export, grid, dim3(256), 0, st, (const float *)pl.lv[0].out[mc.merge_layer], lm.cout_pad,
+                               s.scale, s.shift, s.mode, lm.cout, npts, phi);
+        }
+        if (fine) {
+            rc = launch_level(ctx, 1, pl, g, rows, pl.mask, (flags & PIFU_Q_NO_FINE_MASK) ? 0 : 2,
+                              fine_out ? fine_out + pt0 : nullptr, ctx->mlp[1].nlayers, st);
+            if (rc != PIFU_OK) return rc;
+        }
+    }
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib, int64_t chunk, int flags,
+               float *pred_fine, float *pred_coarse, float *phi, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && points && calib, PIFU_ERR_INVALID, "pifu_query: null argument");
+    PIFU_REQUIRE(!phi || n <= chunk, PIFU_ERR_INVALID, "pifu_query: phi is only defined for a single chunk (n <= chunk)");
+    return pifu_query_impl(ctx, 0, points, n, nullptr, nullptr, nullptr, 0, calib, chunk, flags, pred_fine, pred_coarse,
+                           phi, 0.f, nullptr, (hipStream_t)stream);
+}
+
+int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_inv, const float *calib,
+                      const int64_t *index, int64_t first, int64_t count, int64_t chunk, int flags, float *pred,
+                      pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && res && calib_inv && calib && pred, PIFU_ERR_INVALID, "pifu_eval_lattice: null argument");
+    PIFU_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0, PIFU_ERR_INVALID, "pifu_eval_lattice: bad resolution");
+    const bool coarse_only = flags & PIFU_Q_COARSE_ONLY;
+    return pifu_query_impl(ctx, index ? 2 : 1, nullptr, count, res, calib_inv, index, first, calib, chunk, flags,
+                           coarse_only ? nullptr : pred, coarse_only ? pred : nullptr, nullptr, 0.f, nullptr, (hipStream_t)stream);
+}
+
+int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta, float *normals,
+                     pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && verts && calib && normals, PIFU_ERR_INVALID, "pifu_calc_normal: null argument");
+    PIFU_REQUIRE(n > 0, PIFU_ERR_INVALID, "pifu_calc_normal: empty vertex batch (the reference raises here too)");
+    float *pred4 = nullptr;
+    int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * n, PIFU_Q_NO_FINE_MASK,
+                             nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
+    if (rc != PIFU_OK) return rc;
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)pred4, n, normals);
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}

@@ -1,0 +1,180 @@
+"""Grid evaluation, marching cubes and OBJ output: drop-in for the reference's `mesh_util.py`.
+
+Same function names / arguments / return values / error behaviour as `mesh_util.py:12-198`, but the grid
+never exists on the host: lattice points are generated on the device from their indices, the float64 SDF
+and the octree state stay in HBM, and marching cubes (Lewiner, scikit-image 0.18.3 semantics) runs as
+HIP kernels.  Everything computes through the C ABI in `include/pifuhd_hip.h`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+from numpy.linalg import inv
+
+from . import _lib
+from .nets import PIFuMRNet, PIFuNetwNML, _ptr, _stream_ptr
+
+
+def create_grid(resX, resY, resZ, b_min=np.array([-1, -1, -1]), b_max=np.array([1, 1, 1]), transform=None):
+    """`create_grid` (`mesh_util.py:12-38`).  Kept for API compatibility (small grids / custom fields);
+    `reconstruction()` does not call it - points are generated on the device."""
+    coords = np.mgrid[:resX, :resY, :resZ].reshape(3, -1).astype(np.float64)
+    mat = np.eye(4)
+    length = np.asarray(b_max, dtype=np.float64) - np.asarray(b_min, dtype=np.float64)
+    mat[0, 0], mat[1, 1], mat[2, 2] = length[0] / resX, length[1] / resY, length[2] / resZ
+    mat[0:3, 3] = b_min
+    coords = coords * np.diag(mat)[:3, None] + mat[:3, 3:4]
+    if transform is not None:
+        coords = np.matmul(transform[:3, :3], coords) + transform[:3, 3:4]
+        mat = np.matmul(transform, mat)
+    return coords.reshape(3, resX, resY, resZ), mat
+
+
+def _ctx_of(net):
+    if isinstance(net, (PIFuMRNet, PIFuNetwNML)):
+        return net._ctx
+    raise TypeError('net must be a pifuhd_amd PIFuMRNet / PIFuNetwNML')
+
+
+def eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree, init_resolution=64, threshold=0.05,
+                     full_coarse=False):
+    """Device-resident eval_grid / eval_grid_octree for one of our nets.  Returns (sdf float64 device
+    tensor [R,R,R], number of evaluated points)."""
+    ctx = _ctx_of(net)
+    dev = ctx.device
+    R = int(resolution)
+    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
+    calib_inv = np.ascontiguousarray(inv(calib.astype(np.float64)))        # mesh_util.py:61-62
+    sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
+    notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8) if use_octree else None
+    flags = 0
+    if isinstance(net, PIFuNetwNML):
+        flags |= _lib.Q_COARSE_ONLY
+    elif full_coarse:
+        flags |= _lib.Q_FULL_COARSE
+    n_eval = C.c_int64(0)
+    _lib.call('pifu_eval_grid', ctx.h, R, calib_inv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+              int(num_samples), int(init_resolution) if use_octree else 0, float(threshold), flags, _ptr(sdf),
+              _ptr(notproc), C.byref(n_eval), _stream_ptr(dev))
+    return sdf, n_eval.value
+
+
+def marching_cubes_device(ctx, volume, level):
+    """Lewiner marching cubes on a device volume (float32 or float64 torch tensor [n0,n1,n2]); returns
+    device tensors (verts float32 [V,3], faces int32 [F,3]).  Raises ValueError / RuntimeError exactly
+    where scikit-image does."""
+    dev = ctx.device
+    vol = volume.contiguous()
+    if vol.dim() != 3 or min(vol.shape) < 2:
+        raise ValueError('Input array must be at least 2x2x2.')
+    dtype = {torch.float32: 0, torch.float64: 1}[vol.dtype]
+    nv, nf = C.c_int64(0), C.c_int64(0)
+    try:
+        _lib.call('pifu_mc_count', ctx.h, _ptr(vol), dtype, vol.shape[0], vol.shape[1], vol.shape[2], float(level),
+                  C.byref(nv), C.byref(nf), _stream_ptr(dev))
+    except _lib.PifuError as e:
+        if e.code == _lib.ERR_MC_LEVEL:
+            raise ValueError(e.message)
+        if e.code == _lib.ERR_MC_EMPTY:
+            raise RuntimeError(e.message)
+        raise
+    verts = torch.empty(nv.value, 3, device=dev, dtype=torch.float32)
+    faces = torch.empty(nf.value, 3, device=dev, dtype=torch.int32)
+    _lib.call('pifu_mc_emit', ctx.h, _ptr(verts), _ptr(faces), _stream_ptr(dev))
+    return verts, faces
+
+
+def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
+                   num_samples=10000, transform=None, return_sdf=False):
+    """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
+    values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
+    [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty."""
+    try:
+        ctx = _ctx_of(net)
+        sdf, _ = eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree)
+    except _lib.PifuError:
+        raise
+    try:
+        verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
+        verts = verts_d.cpu().numpy()
+        faces = faces_d.cpu().numpy()
+        calib_inv = inv(calib_tensor[0].detach().cpu().numpy().astype(np.float64))
+        mat = np.eye(4)
+        mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
+        mat[0:3, 3] = -1.0
+        trans_mat = np.matmul(calib_inv, mat)
+        verts = (np.matmul(trans_mat[:3, :3], verts.T) + trans_mat[:3, 3:4]).T          # mesh_util.py:87-89
+        if np.linalg.det(trans_mat[:3, :3]) < 0.0:
+            faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
+        normals = np.zeros((0, 3), np.float32)
+        values = np.zeros((0,), np.float32)
+        if return_sdf:
+            return verts, faces, normals, values, sdf
+        return verts, faces, normals, values
+    except (ValueError, RuntimeError):
+        print('error cannot marching cubes')                                             # mesh_util.py:94-96
+        return -1
+
+
+# ------------------------------------------------------------------------------------------------
+# Generic host-callback variants (same signatures as the reference).  The octree bookkeeping still runs
+# in the HIP kernels; only `eval_func` (numpy in, numpy out) is the caller's.
+# ------------------------------------------------------------------------------------------------
+def batch_eval(points, eval_func, num_samples=512 * 512 * 512):
+    """`batch_eval` (`mesh_util.py:98-114`)."""
+    n = points.shape[1]
+    sdf = np.zeros(n)
+    for s in range(0, n, num_samples):
+        sdf[s:s + num_samples] = eval_func(points[:, s:s + num_samples])
+    return sdf
+
+
+def eval_grid(coords, eval_func, num_samples=512 * 512 * 512):
+    """`eval_grid` (`mesh_util.py:116-120`)."""
+    resolution = coords.shape[1:4]
+    return batch_eval(coords.reshape([3, -1]), eval_func, num_samples=num_samples).reshape(resolution)
+
+
+def eval_grid_octree(coords, eval_func, init_resolution=64, threshold=0.05, num_samples=512 * 512 * 512,
+                     device='cuda'):
+    """`eval_grid_octree` (`mesh_util.py:124-187`) for an arbitrary host `eval_func`; cubic grids."""
+    R = coords.shape[1]
+    if coords.shape[2] != R or coords.shape[3] != R:
+        raise NotImplementedError('cubic grids only')
+    from .nets import _Ctx
+    ctx = _Ctx(device)
+    dev = ctx.device
+    st = _stream_ptr(dev)
+    sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
+    notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8)
+    _lib.call('pifu_octree_begin', ctx.h, R, _ptr(sdf), _ptr(notproc), st)
+    flat = coords.reshape(3, -1)
+    reso = R // init_resolution
+    while reso > 0:
+        cnt = C.c_int64(0)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st)
+        n = cnt.value
+        idx = torch.empty(max(n, 1), device=dev, dtype=torch.int64)
+        vals = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        if n:
+            _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
+            pts = flat[:, idx[:n].cpu().numpy()]
+            out = batch_eval(pts, eval_func, num_samples=num_samples)
+            vals[:n] = torch.from_numpy(out.astype(np.float32)).to(dev)
+        _lib.call('pifu_octree_commit', ctx.h, R, reso, float(threshold), _ptr(idx), _ptr(vals), n, _ptr(sdf),
+                  _ptr(notproc), st)
+        if reso <= 1:
+            break
+        reso //= 2
+    return sdf.cpu().numpy()
+
+
+def save_obj_mesh_with_color(mesh_path, verts, faces, colors):
+    """`save_obj_mesh_with_color` (`mesh_util.py:189-198`), native writer."""
+    v = np.ascontiguousarray(verts, dtype=np.float64)
+    c = np.ascontiguousarray(colors, dtype=np.float64)
+    f = np.ascontiguousarray(faces, dtype=np.int32)
+    _lib.call('pifu_write_obj', str(mesh_path).encode(), v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+              len(v), f.ctypes.data_as(C.c_void_p), len(f))

@@ -1,0 +1,359 @@
+"""Host-side mirrors of the reference's network classes for the hot path.
+
+`PIFuNetwNML` (coarse level + normal nets, reference `PIFuNetwNML.py:17-141`) and `PIFuMRNet` (fine level,
+reference `PIFuMRNet.py:15-243`) keep the reference's method names, argument meaning, cached attributes
+(`preds`, `phi`, `intermediate_preds_list`, `im_feat_list`, `nmlF`, `nmlB`, `nmls`, `preds_low`,
+`preds_interm`) and call order (filter before query), but hold no torch modules: weights are packed into
+a `pifu_ctx` (C ABI, `include/pifuhd_hip.h`) and every query runs in hand-written HIP kernels.
+torch tensors are used for device memory and streams only.
+
+Out of scope here (training-time arguments of the same methods): `labels`, `transforms`, perspective
+projection, multi-view `B2 > 1`; they raise NotImplementedError instead of silently differing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, encoder
+
+_NORM_CODE = {'group': _lib.NORM_GROUP}
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host_f32(t):
+    a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class _Ctx:
+    """Owns one `pifu_ctx` on one device."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.PifuError(_lib.ERR_INVALID, 'the HIP path needs a GPU device (no CPU fallback)')
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device('cuda', idx)
+        h = C.c_void_p()
+        _lib.call('pifu_ctx_create', idx, C.byref(h))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                _lib.load().pifu_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _mlp_norm_code(mlp_norm, training):
+    if mlp_norm == 'group':
+        return _lib.NORM_GROUP
+    if mlp_norm == 'batch':
+        return _lib.NORM_BATCH_TRAIN if training else _lib.NORM_BATCH_EVAL
+    return _lib.NORM_NONE                                  # MLP.py:65-66: anything else = no norm
+
+
+def _push_mlp(ctx, level, sd, prefix, dims, res_layers, merge_layer, norm_code):
+    dims_a = (C.c_int32 * len(dims))(*dims)
+    res_a = (C.c_int32 * max(1, len(res_layers)))(*res_layers)
+    _lib.call('pifu_mlp_define', ctx.h, level, dims_a, len(dims), res_a, len(res_layers), merge_layer, norm_code)
+    n = len(dims) - 1
+    keep = []
+    for i in range(n):
+        w, wp = _host_f32(sd[f'{prefix}.filters.{i}.weight'].reshape(dims[i + 1], -1))
+        b, bp = _host_f32(sd[f'{prefix}.filters.{i}.bias'])
+        g = be = rm = rv = None
+        gp = bep = rmp = rvp = None
+        if i != n - 1 and norm_code != _lib.NORM_NONE:
+            g, gp = _host_f32(sd[f'{prefix}.norms.{i}.weight'])
+            be, bep = _host_f32(sd[f'{prefix}.norms.{i}.bias'])
+            if norm_code in (_lib.NORM_BATCH_EVAL, _lib.NORM_BATCH_TRAIN):
+                rm, rmp = _host_f32(sd[f'{prefix}.norms.{i}.running_mean'])
+                rv, rvp = _host_f32(sd[f'{prefix}.norms.{i}.running_var'])
+        keep.append((w, b, g, be, rm, rv))
+        _lib.call('pifu_mlp_set_layer', ctx.h, level, i, wp, bp, gp, bep, rmp, rvp)
+
+
+class BasePIFuNet:
+    """API shell (`BasePIFuNet.py:67-148`)."""
+
+    def __init__(self, projection_mode='orthogonal'):
+        if projection_mode not in ('orthogonal', 'otthogonal'):      # 'otthogonal': PIFuMRNet.py:22 default typo
+            raise NotImplementedError('only the orthogonal projection is on the reconstruction path '
+                                      '(readData.py:34); perspective is out of scope')
+        self.name = 'base'
+        self.preds = None
+        self.labels = None
+        self.nmls = None
+        self.training = True
+
+    def forward(self, points, images, calibs, transforms=None):
+        self.filter(images)
+        self.query(points, calibs, transforms)
+        return self.get_preds()
+
+    __call__ = forward
+
+    def get_preds(self):
+        return self.preds
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @staticmethod
+    def _check_unsupported(transforms, labels):
+        if transforms is not None:
+            raise NotImplementedError('screen-space `transforms` are never used on the reconstruction path')
+        if labels is not None:
+            raise NotImplementedError('`labels` (training supervision) is out of scope of the HIP path')
+
+
+class PIFuNetwNML(BasePIFuNet):
+    """Coarse level: normal nets + HGFilter + SurfaceClassifier (`PIFuNetwNML.py:17-141`)."""
+
+    def __init__(self, opt, projection_mode='orthogonal', device='cuda'):
+        super().__init__(projection_mode)
+        self.name = 'hg_pifu'
+        self.opt = opt
+        self._ctx = _Ctx(device)
+        self.device = self._ctx.device
+        self._sd = None
+        self.im_feat_list = []
+        self.normx = None
+        self.phi = None
+        self.intermediate_preds_list = []
+        self.nmlF = None
+        self.nmlB = None
+        self.netF = 'netF' if getattr(opt, 'use_front_normal', False) else None
+        self.netB = 'netB' if getattr(opt, 'use_back_normal', False) else None
+        self._last_n = 0
+
+    # -- parameters --------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, _prefix=''):
+        from . import synth
+        spec = synth.coarse_spec(self.opt, _prefix)
+        missing = [k for k in spec if k not in state_dict]
+        if strict and missing:
+            raise KeyError(f'missing keys in state dict: {missing[:5]} ...')
+        self._sd = {k[len(_prefix):]: state_dict[k].detach().to(self.device, torch.float32)
+                    if state_dict[k].dtype.is_floating_point else state_dict[k]
+                    for k in spec if k in state_dict}
+        self._push_weights()
+
+    def _push_weights(self):
+        o = self.opt
+        # eval mode on the reconstruction path (reconstruction.py:288-289): running stats for 'batch'
+        code = _mlp_norm_code(o.mlp_norm, self.training)
+        _push_mlp(self._ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers),
+                  int(o.merge_layer), code)
+        _lib.call('pifu_set_depth_normalizer', self._ctx.h, float(o.loadSize // 2), float(o.z_size))
+
+    def train(self, mode=True):
+        changed = mode != self.training
+        self.training = mode
+        if changed and self._sd is not None and self.opt.mlp_norm == 'batch':
+            self._push_weights()
+        return self
+
+    # -- filter ------------------------------------------------------------------------------------
+    def filter(self, images):
+        """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`)."""
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter()')
+        images = images.to(self.device, torch.float32)
+        feats, self.normx, self.nmlF, self.nmlB = encoder.filter_coarse(self._sd, self.opt, images,
+                                                                        bn_training=self.training)
+        self.im_feat_list = feats if self.training else [feats[-1]]
+        self._set_features(self.im_feat_list[-1])
+
+    def _set_features(self, feat):
+        feat = feat.contiguous()
+        _, c, h, w = feat.shape
+        _lib.call('pifu_set_features', self._ctx.h, _lib.LEVEL_COARSE, _ptr(feat), c, h, w, _stream_ptr(self.device))
+        self._feat_keepalive = feat
+
+    def set_features(self, feat):
+        """Install a precomputed coarse feature map [1,C,H,W] (what filter() would cache)."""
+        feat = feat.to(self.device, torch.float32)
+        self.im_feat_list = [feat]
+        self._set_features(feat)
+
+    # -- query -------------------------------------------------------------------------------------
+    def query(self, points, calibs, transforms=None, labels=None, update_pred=True, update_phi=True):
+        """`PIFuNetwNML.query` (`PIFuNetwNML.py:99-141`): points [1,3,N], calibs [1,4,4]."""
+        self._check_unsupported(transforms, labels)
+        if not self.im_feat_list:
+            raise _lib.PifuError(_lib.ERR_STATE, 'filter() must precede query()')
+        pts = points.to(self.device, torch.float32).contiguous()
+        if pts.dim() != 3 or pts.shape[0] != 1 or pts.shape[1] != 3:
+            raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
+        n = pts.shape[2]
+        calib, calib_p = _host_f32(calibs[0])
+        pred = torch.empty(n, device=self.device, dtype=torch.float32)
+        cphi = self.opt.mlp_dim[(self.opt.merge_layer if self.opt.merge_layer > 0 else len(self.opt.mlp_dim) // 2) + 1]
+        phi = torch.empty(cphi, n, device=self.device, dtype=torch.float32) if update_phi else None
+        _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, _lib.Q_COARSE_ONLY, None, _ptr(pred),
+                  _ptr(phi), _stream_ptr(self.device))
+        if update_phi:
+            self.phi = phi[None]
+        if update_pred:
+            self.preds = pred[None, None]
+            self.intermediate_preds_list = [self.preds]
+
+
+class PIFuMRNet(BasePIFuNet):
+    """Fine level (`PIFuMRNet.py:15-243`); owns a reference to the coarse net `netG`."""
+
+    def __init__(self, opt, netG, projection_mode='orthogonal'):
+        super().__init__(projection_mode)
+        self.name = 'hg_pifu'
+        self.opt = opt
+        self.netG = netG
+        self._ctx = netG._ctx
+        self.device = netG.device
+        self._sd = None
+        self.im_feat_list = []
+        self.preds_interm = None
+        self.preds_low = None
+        self.normx = None
+        self.training = True          # a freshly constructed module is in train mode (SURVEY C-2)
+
+    def train(self, mode=True):
+        """`PIFuMRNet.train` (`PIFuMRNet.py:59-69`): netG is forced to eval unless train_full_pifu."""
+        changed = mode != self.training
+        self.training = mode
+        if not getattr(self.opt, 'train_full_pifu', False):
+            self.netG.eval()
+        if changed and self._sd is not None and self.opt.mlp_norm == 'batch':
+            self._push_weights()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        from . import synth
+        self.netG.load_state_dict(state_dict, strict, _prefix='netG.')
+        own = {}
+        synth.filter_keys('image_filter', self.opt.num_stack, self.opt.hg_depth,
+                          synth.image_filter_in_channels(self.netG.opt), self.opt.hg_dim, self.opt.norm, 'no_down', own)
+        synth.mlp_keys('mlp', self.opt.mlp_dim, self.opt.mlp_res_layers, self.opt.mlp_norm, own)
+        missing = [k for k in own if k not in state_dict]
+        if strict and missing:
+            raise KeyError(f'missing keys in state dict: {missing[:5]} ...')
+        self._sd = {k: state_dict[k].detach().to(self.device, torch.float32)
+                    if state_dict[k].dtype.is_floating_point else state_dict[k] for k in own if k in state_dict}
+        self._push_weights()
+
+    def _push_weights(self):
+        o = self.opt
+        code = _mlp_norm_code(o.mlp_norm, self.training)      # train mode => per-chunk batch statistics (C-2)
+        _push_mlp(self._ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
+
+    # -- filter ------------------------------------------------------------------------------------
+    def filter_global(self, images):
+        """`PIFuMRNet.filter_global` (`PIFuMRNet.py:71-81`)."""
+        self.netG.filter(images)
+
+    def filter_local(self, images, rect=None):
+        """`PIFuMRNet.filter_local` (`PIFuMRNet.py:83-118`): images [1,1,C,H,W]."""
+        if rect is not None:
+            raise NotImplementedError('`rect` crops are never used on the reconstruction path')
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter_local()')
+        images = images.to(self.device, torch.float32)
+        if images.dim() != 5 or images.shape[0] != 1 or images.shape[1] != 1:
+            raise NotImplementedError('images [1,1,C,H,W] (single view, the reconstruction path)')
+        feats, self.normx = encoder.filter_fine(self._sd, self.opt, self.netG.opt, images[:, 0], self.netG.nmlF,
+                                                self.netG.nmlB, bn_training=self.training)
+        self.im_feat_list = feats if self.training else [feats[-1]]
+        self._set_features(self.im_feat_list[-1])
+
+    def _set_features(self, feat):
+        feat = feat.contiguous()
+        _, c, h, w = feat.shape
+        _lib.call('pifu_set_features', self._ctx.h, _lib.LEVEL_FINE, _ptr(feat), c, h, w, _stream_ptr(self.device))
+        self._feat_keepalive = feat
+
+    def set_features(self, feat):
+        feat = feat.to(self.device, torch.float32)
+        self.im_feat_list = [feat]
+        self._set_features(feat)
+
+    # -- query -------------------------------------------------------------------------------------
+    def query(self, points, calib_local, calib_global=None, transforms=None, labels=None):
+        """`PIFuMRNet.query` (`PIFuMRNet.py:119-186`), 3-argument form used by reconstruction:
+        points [1,3,N], calib_local [1,4,4]."""
+        self._check_unsupported(transforms, labels)
+        if calib_global is not None:
+            if calib_local.shape[1] != 1:
+                raise NotImplementedError('multi-view B2 > 1 is out of scope')
+            points = points[:, 0]
+            calib_local = calib_local[:, 0]
+            if not torch.equal(calib_local.cpu(), calib_global.cpu()):
+                raise NotImplementedError('different local/global calibrations (crop training) are out of scope')
+        if not self.im_feat_list or not self.netG.im_feat_list:
+            raise _lib.PifuError(_lib.ERR_STATE, 'filter_global()/filter_local() must precede query()')
+        pts = points.to(self.device, torch.float32).contiguous()
+        if pts.dim() != 3 or pts.shape[0] != 1 or pts.shape[1] != 3:
+            raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
+        n = pts.shape[2]
+        calib, calib_p = _host_f32(calib_local[0])
+        fine = torch.empty(n, device=self.device, dtype=torch.float32)
+        coarse = torch.empty(n, device=self.device, dtype=torch.float32)
+        g = self.netG
+        cphi = g.opt.mlp_dim[(g.opt.merge_layer if g.opt.merge_layer > 0 else len(g.opt.mlp_dim) // 2) + 1]
+        phi = torch.empty(cphi, n, device=self.device, dtype=torch.float32)
+        _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, 0, _ptr(fine), _ptr(coarse), _ptr(phi),
+                  _stream_ptr(self.device))
+        # attributes the reference leaves behind (PIFuMRNet.py:154-181, PIFuNetwNML.py:137-141)
+        g.phi = phi[None]
+        g.preds = coarse[None, None]
+        g.intermediate_preds_list = [g.preds]
+        self.preds = fine[None, None]
+        self.preds_interm = self.preds[None]
+        self.preds_low = g.preds[None]
+
+    def calc_normal(self, points, calib_local, calib_global, transforms=None, labels=None, delta=0.001,
+                    fd_type='forward'):
+        """`PIFuMRNet.calc_normal` (`PIFuMRNet.py:188-243`): points [1,1,3,n] -> self.nmls [1,3,n]."""
+        self._check_unsupported(transforms, labels)
+        pts = points.to(self.device, torch.float32)
+        if pts.dim() != 4 or pts.shape[0] != 1 or pts.shape[1] != 1 or pts.shape[2] != 3:
+            raise NotImplementedError('points [1,1,3,n] (single view, the reconstruction path)')
+        pts = pts[0, 0].contiguous()
+        n = pts.shape[1]
+        if n == 0:
+            # the reference crashes inside Conv1d on an empty slice (SURVEY C-6)
+            raise RuntimeError('calc_normal on an empty vertex slice')
+        calib, calib_p = _host_f32(calib_global[0])
+        out = torch.empty(3, n, device=self.device, dtype=torch.float32)
+        _lib.call('pifu_calc_normal', self._ctx.h, _ptr(pts), n, calib_p, float(delta), _ptr(out),
+                  _stream_ptr(self.device))
+        self.nmls = out[None]
+
+    def get_im_feat(self):
+        return self.im_feat_list[-1]
+
+
+def build_nets(opt_coarse, opt_fine, state_dict, device='cuda'):
+    """What `recon()` does before its loop (`reconstruction.py:283-304`): build both nets, load one state
+    dict, put ONLY netG in eval mode."""
+    netG = PIFuNetwNML(opt_coarse, 'orthogonal', device)
+    netMR = PIFuMRNet(opt_fine, netG, 'orthogonal')
+    netG.eval()
+    netMR.load_state_dict(state_dict)
+    return netG, netMR

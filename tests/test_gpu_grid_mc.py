@@ -1,0 +1,155 @@
+"""HIP grid evaluation (dense + octree) and marching cubes vs the oracle / golden fixtures.
+Integer and index work is held to bit-exactness."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import calib_tensor, golden_nets, noisy_field, seeded_features
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def mc_gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'mc_small.npz'))
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from pifuhd_amd.nets import _Ctx
+    return _Ctx('cuda')
+
+
+def _mc(ctx, vol, level=0.5):
+    from pifuhd_amd import mesh_util
+    v, f = mesh_util.marching_cubes_device(ctx, torch.from_numpy(np.ascontiguousarray(vol)).cuda(), level)
+    return v.cpu().numpy(), f.cpu().numpy()
+
+
+def _same(v, f, gv, gf):
+    return (v.shape == gv.shape and f.shape == gf.shape and np.array_equal(f, gf)
+            and np.array_equal(v.view(np.uint32), gv.view(np.uint32)))
+
+
+def test_mc_known_answers_noise_and_ellipsoid(ctx, mc_gold):
+    g = mc_gold
+    for i in range(int(g['kat_n'][0])):
+        v, f = _mc(ctx, g[f'kat{i}_vol'])
+        assert _same(v, f, g[f'kat{i}_v'], g[f'kat{i}_f']), f'kat{i}'
+    for i in range(int(g['noise_n'][0])):
+        v, f = _mc(ctx, g[f'noise{i}_vol'])
+        assert _same(v, f, g[f'noise{i}_v'], g[f'noise{i}_f']), f'noise{i}'
+    v, f = _mc(ctx, g['ell40_vol'])
+    assert _same(v, f, g['ell40_v'], g['ell40_f'])
+    # float64 input is cast to float32 first, as scikit-image does
+    v, f = _mc(ctx, g['ell40_vol'].astype(np.float64))
+    assert _same(v, f, g['ell40_v'], g['ell40_f'])
+
+
+def test_mc_tie_cells(ctx, mc_gold):
+    """4000 single cells with one-decimal values: exercises every eps / >= branch of the Lewiner tests."""
+    g = mc_gold
+    ov = np.concatenate([[0], np.cumsum(g['cells_nv'])])
+    of = np.concatenate([[0], np.cumsum(g['cells_nf'])])
+    bad = []
+    for i, c in enumerate(g['cells_vol']):
+        try:
+            v, f = _mc(ctx, c)
+        except (ValueError, RuntimeError):
+            v, f = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
+        if not _same(v, f, g['cells_v'][ov[i]:ov[i + 1]], g['cells_f'][of[i]:of[i + 1]]):
+            bad.append(i)
+    assert not bad, bad[:10]
+
+
+def test_mc_errors(ctx):
+    with pytest.raises(ValueError):
+        _mc(ctx, np.zeros((4, 4, 4), np.float32))
+    with pytest.raises(RuntimeError):
+        _mc(ctx, np.full((4, 4, 4), 0.5, np.float32))
+
+
+def test_mc_reference_network_sdfs(ctx, mc_gold, golden_dir):
+    r = np.load(os.path.join(golden_dir, 'recon_small.npz'))
+    for tag in ('dense32', 'oct64'):
+        v, f = _mc(ctx, r[f'{tag}_sdf_f32'])
+        assert [len(v), len(f)] == list(mc_gold[f'{tag}_nv_nf'])
+        assert hashlib.sha256(v.tobytes()).digest() == mc_gold[f'{tag}_v_sha'].tobytes()
+        assert hashlib.sha256(f.tobytes()).digest() == mc_gold[f'{tag}_f_sha'].tobytes()
+
+
+def test_mc_large_vs_oracle(ctx):
+    """128^3 analytic body + noise: faces and vertices bit-exact against the serial oracle."""
+    from oracle import pifu_oracle as O
+    rs = np.random.RandomState(5)
+    R = 128
+    lin = -1 + 2 * np.arange(R) / R
+    X, Y, Z = np.meshgrid(lin, lin, lin, indexing='ij')
+    r = np.sqrt((0.8 * X) ** 2 + (0.45 * Y) ** 2 + (1.6 * Z) ** 2)
+    vol = (1.0 / (1.0 + np.exp(-(0.35 - r) / 0.02)) + 0.05 * (rs.rand(R, R, R) - 0.5)).astype(np.float32)
+    v, f = _mc(ctx, vol)
+    vr, fr = O.marching_cubes_lewiner(vol, 0.5)
+    assert _same(v, f, vr, fr)
+
+
+@pytest.mark.parametrize('R,init', [(32, 4), (64, 8), (64, 16), (64, 64), (48, 6)])
+def test_octree_bookkeeping_bit_exact(golden_dir, R, init):
+    """The device octree (select / commit kernels) with the analytic field of the golden generator:
+    the float64 SDF must be bit-identical to the reference's sequential numpy implementation."""
+    from pifuhd_amd import mesh_util
+    gold = np.load(os.path.join(golden_dir, 'octree_small.npz'))
+    coords, _ = mesh_util.create_grid(R, R, R)
+    calib_inv = np.linalg.inv(np.diag([1.0, -1.0, 1.0, 1.0]))
+    c = coords.reshape(3, -1).T
+    c = np.matmul(np.concatenate([c, np.ones((c.shape[0], 1))], 1), calib_inv.T)[:, :3].T.reshape(3, R, R, R)
+    counts = []
+
+    def f(p):
+        counts.append(p.shape[1])
+        return noisy_field(p)
+    sdf = mesh_util.eval_grid_octree(c, f, init_resolution=init, threshold=0.05, num_samples=5000)
+    assert hashlib.sha256(sdf.tobytes()).digest() == gold[f'oct_{R}_{init}_sha'].tobytes()
+    assert np.array_equal(np.array(counts), gold[f'oct_{R}_{init}_chunks'])
+
+
+def test_network_grid_vs_reference_sdf(golden_dir):
+    """Dense 32^3 and octree 64^3 with the network field: SDF within 1e-4 of the reference's, and the
+    triangle index stream bit-exact against the serial oracle run on the SAME device SDF."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util, nets
+    gold = np.load(os.path.join(golden_dir, 'recon_small.npz'))
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(9)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = calib_tensor()
+    for tag, R, octree in (('dense32', 32, False), ('oct64', 64, True)):
+        res = mesh_util.reconstruction(netMR, 'cuda', calib, R, None, None, 0.5, use_octree=octree, num_samples=5000,
+                                       return_sdf=True)
+        assert res != -1
+        verts, faces, _, _, sdf = res
+        sdf = sdf.cpu().numpy()
+        assert np.abs(sdf - gold[f'{tag}_sdf_f32']).max() < 1e-4
+        vr, fr = O.marching_cubes_lewiner(sdf, 0.5)
+        assert np.array_equal(faces[:, ::-1], fr)
+        # vertex back-transform (mesh_util.py:87-89) in float64
+        calib_inv = np.linalg.inv(calib[0].numpy().astype(np.float64))
+        mat = np.eye(4); mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / R; mat[:3, 3] = -1
+        tm = calib_inv @ mat
+        assert np.array_equal(verts, (tm[:3, :3] @ vr.T.astype(np.float64) + tm[:3, 3:4]).T)
+
+
+def test_obj_writer(tmp_path):
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util
+    rs = np.random.RandomState(3)
+    v = rs.randn(500, 3) * 3
+    c = rs.rand(500, 3)
+    f = rs.randint(0, 500, size=(900, 3)).astype(np.int32)
+    p = tmp_path / 'm.obj'
+    mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
+    assert p.read_text() == O.obj_text(v, f, c)

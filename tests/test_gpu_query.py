@@ -1,0 +1,117 @@
+"""HIP query path vs the CPU oracle and vs the golden vectors generated from the reference.
+Tolerance (north star): occupancy within 1e-4 fp32; in practice ~1e-6 because the MLP GEMMs run on the
+exact-fp32 MFMA."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import calib_tensor, golden_nets, seeded_features, seeded_points
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'query_small.npz'))
+
+
+def _build(mlp_norm='group', feat_seed=7):
+    from pifuhd_amd import nets
+    sd, oc, of = golden_nets(mlp_norm=mlp_norm)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(feat_seed)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    return netG, netMR, sd, oc, of
+
+
+@pytest.mark.parametrize('tag,mlp_norm', [('group', 'group'), ('batch', 'batch'), ('none', 'no')])
+def test_query_matches_reference_golden(gold, tag, mlp_norm):
+    netG, netMR, *_ = _build(mlp_norm)
+    calib = calib_tensor()
+    scale = 1.0 if mlp_norm == 'group' else 3.0
+    netMR.query(seeded_points(3, 700), calib)
+    fine = netMR.get_preds()[0, 0].cpu().numpy()
+    assert np.abs(fine - gold[f'{tag}_a_fine']).max() < TOL * scale
+    assert np.abs(netG.preds[0, 0].cpu().numpy() - gold[f'{tag}_a_coarse']).max() < TOL * scale
+    assert np.abs(netG.phi[0, ::16].cpu().numpy() - gold[f'{tag}_a_phi_sub']).max() < 2e-3 * scale
+    assert np.array_equal(fine == 0, gold[f'{tag}_a_fine'] == 0)          # bounding-box mask
+    # chunked evaluation: 500 / 500 / 200
+    pts = seeded_points(4, 1200, lim=1.0)
+    out = []
+    for s in range(0, 1200, 500):
+        netMR.query(pts[:, :, s:s + 500], calib)
+        out.append(netMR.get_preds()[0, 0].cpu().numpy())
+    assert np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max() < TOL * scale
+    # coarse-only net
+    netG.query(seeded_points(5, 300), calib)
+    assert np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max() < TOL * scale
+
+
+def test_chunked_c_abi_equals_per_chunk_calls(gold):
+    """pifu_query with chunk < n must reproduce consecutive reference calls (GroupNorm per chunk)."""
+    import ctypes as C
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netG, netMR, *_ = _build()
+    pts = seeded_points(4, 1200, lim=1.0).cuda().contiguous()
+    calib = np.ascontiguousarray(calib_tensor()[0].numpy())
+    out = torch.empty(1200, device='cuda')
+    _lib.call('pifu_query', netMR._ctx.h, _ptr(pts), 1200, calib.ctypes.data_as(C.c_void_p), 500, 0, _ptr(out), None,
+              None, _stream_ptr(netMR.device))
+    assert np.abs(out.cpu().numpy() - gold['group_b_fine']).max() < TOL
+
+
+def test_query_vs_oracle_large_chunk():
+    """5000-point chunks (gen_mesh's num_samples) incl. a ragged last chunk, against the oracle."""
+    from oracle import pifu_oracle as O
+    import ctypes as C
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netG, netMR, sd, oc, of = _build()
+    n = 5000 * 2 + 1234
+    pts = seeded_points(11, n, lim=1.05)
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    calib = calib_tensor()
+    with torch.no_grad():
+        want = np.concatenate([ref.query(pts[:, :, s:s + 5000], calib)[0, 0].numpy() for s in range(0, n, 5000)])
+    out = torch.empty(n, device='cuda')
+    cal = np.ascontiguousarray(calib[0].numpy())
+    _lib.call('pifu_query', netMR._ctx.h, _ptr(pts.cuda().contiguous()), n, cal.ctypes.data_as(C.c_void_p), 5000,
+              _lib.Q_FULL_COARSE, _ptr(out), None, None, _stream_ptr(netMR.device))
+    got = out.cpu().numpy()
+    assert np.abs(got - want).max() < TOL
+    # determinism: bit-identical on a second run (no atomics in the statistics)
+    out2 = torch.empty(n, device='cuda')
+    _lib.call('pifu_query', netMR._ctx.h, _ptr(pts.cuda().contiguous()), n, cal.ctypes.data_as(C.c_void_p), 5000,
+              0, _ptr(out2), None, None, _stream_ptr(netMR.device))
+    assert torch.equal(out, out2)
+
+
+def test_calc_normal(gold):
+    netG, netMR, *_ = _build()
+    calib = calib_tensor()
+    pts = seeded_points(6, 150, lim=0.9)
+    netMR.calc_normal(pts[:, None], calib[:, None], calib)
+    n = netMR.nmls[0].cpu().numpy()
+    ref = gold['group_d_nml']
+    cos = (n * ref).sum(0)
+    # forward differences with delta = 1e-3 amplify fp32 rounding ~1e3x: compare by angle
+    assert np.median(cos) > 0.9999
+    assert (cos > 0.99).mean() > 0.9
+    assert np.allclose(np.linalg.norm(n, axis=0), 1.0, atol=1e-5)
+
+
+def test_errors_are_loud():
+    from pifuhd_amd import _lib, config, nets
+    oc = config.coarse_opt()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    with pytest.raises(_lib.PifuError):
+        netG.query(seeded_points(1, 10), calib_tensor())        # filter must precede query
+    with pytest.raises(NotImplementedError):
+        nets.PIFuNetwNML(oc, 'perspective', 'cuda')
