@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: occupancy Mqueries/s of the two-level PIFuHD query over a dense evaluation grid.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one batch of synthetic input = one dense grid evaluation:
+256^3 lattice points per GPU (BASELINE.json configs[1]: coarse+fine PIFuMRNet, 1024 px input, fp32),
+cut into the reference's 5000-point query() chunks (GroupNorm couples a chunk, so chunking is part of
+the numerical contract).  With N GPUs the lattice is (N*256) x 256 x 256: rank r evaluates a contiguous
+range of whole chunks (an axis-0 slab) and ONE RCCL all-gather of the fp32 occupancy field follows,
+inside the timed region (weak scaling: 256^3 queries per GPU).  Feature maps come from the real
+filter_global / filter_local of a synthetic 1024 px image with name-seeded random weights and are
+resident in HBM before the timed region, as are the weights; lattice points are generated on the device.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel k_mlp_gemm (exact-fp32 MFMA): algorithmic
+FLOPs of its launches / their summed HIP-event durations, against the 157.3 TFLOP/s fp32-matrix peak.
+`cpu_baseline` times the CPU oracle (kind "port": the reference's Python cannot travel to the GPU box) on
+a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_QUERY = 2916098            # coarse MLP 2,100,738 + fine MLP 815,360
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--res', type=int, default=256, help='lattice points per axis per GPU slab')
+    ap.add_argument('--chunk', type=int, default=5000)
+    ap.add_argument('--cpu-chunks', type=int, default=200, help='chunks of the workload timed on the CPU oracle')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-genmesh', action='store_true')
+    ap.add_argument('--genmesh-res', type=int, default=512)
+    ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
+                    help="feature maps from the real encoders (filter) or seeded random maps of the same shape")
+    ap.add_argument('--lean', action='store_true', help='skip the coarse MLP layers whose output nobody reads')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import _lib, config, dist as pdist, nets, synth
+    from pifuhd_amd.nets import _stream_ptr
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    # ---- model + inputs (outside the timed region) ---------------------------------------------------
+    oc = config.coarse_opt()
+    of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    netG, netMR = nets.build_nets(oc, of, sd, dev)
+    def log(msg):
+        print(f'[bench r{rank} {time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
+    log('weights ready')
+    data = synth.synthetic_inputs(1024, 3, seed=rank)
+    if args.features == 'filter':
+        netMR.filter_global(data['img_512'].to(dev))
+        netMR.filter_local(data['img'].to(dev)[:, None])
+    else:
+        gfe = torch.Generator().manual_seed(4242 + rank)
+        netG.set_features(torch.randn(1, 256, 128, 128, generator=gfe))
+        netMR.set_features(torch.randn(1, 16, 512, 512, generator=gfe))
+    torch.cuda.synchronize(dev)
+    log(f'feature maps ready ({args.features})')
+    calib = data['calib']
+    torch.cuda.synchronize(dev)
+
+    R = args.res
+    res = (world * R, R, R)
+    total = res[0] * res[1] * res[2]
+    flags = 0 if args.lean else _lib.Q_FULL_COARSE
+    h = netMR._ctx.h
+    _lib.call('pifu_reserve', h, 262144)
+
+    def step():
+        return pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, flags)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    log('warm-up done')
+    _lib.call('pifu_profile_read', h, None, None, None, 1)
+    _lib.call('pifu_profile_enable', h, 1)
+    fence()
+    t0 = time.perf_counter()
+    field = None
+    for _ in range(args.steps):
+        field = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    log(f'timed region done: {elapsed:.3f} s')
+    _lib.call('pifu_profile_enable', h, 0)
+    gemm_ms, gemm_n, gemm_flops = C.c_double(0), C.c_int64(0), C.c_double(0)
+    _lib.call('pifu_profile_read', h, C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_flops), 1)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    value = total * args.steps / elapsed / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    achieved = gemm_flops.value / (gemm_ms.value * 1e-3) / 1e12 if gemm_ms.value > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('k_mlp_gemm_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    out = {
+        'metric': 'occupancy_queries_throughput', 'value': round(value, 3), 'unit': 'Mqueries/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': f'dense {res[0]}x{res[1]}x{res[2]} lattice ({R}^3 per GPU, axis-0 chunk-range slabs, RCCL '
+                        f'all-gather of the fp32 field), coarse+fine PIFuMRNet query, chunk {args.chunk}, '
+                        f'1024px RGB image + 512px, name-seeded weights',
+            'queries_per_step': total, 'chunk': args.chunk, 'coarse_tail': 'skipped' if args.lean else 'computed',
+            'flop_per_query_canonical': FLOP_PER_QUERY,
+        },
+        'whole_path_tflops': round(value * 1e6 * FLOP_PER_QUERY / 1e12 * (0.9547 if args.lean else 1.0), 2),
+        'roofline': {
+            'kernel': 'k_mlp_gemm', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': traffic,
+            'launches': gemm_n.value, 'avg_launch_ms': round(gemm_ms.value / max(gemm_n.value, 1), 4),
+            'alg_gflop_per_launch': round(gemm_flops.value / max(gemm_n.value, 1) / 1e9, 3),
+            'gemm_time_share_of_step': round(gemm_ms.value * 1e-3 / elapsed, 4),
+        },
+    }
+
+    # ---- parity spot check + CPU baseline (oracle = checker; never the thing measured as `value`) -----
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pifu_oracle as O
+        torch.set_num_threads(os.cpu_count() or 1)
+        ref = O.OracleNets(sd, oc, of, fine_training=True)
+        ref.feat_coarse = netG.im_feat_list[-1].cpu()
+        ref.feat_fine = netMR.im_feat_list[-1].cpu()
+        calib_inv = np.linalg.inv(calib[0].numpy().astype(np.float64))
+        nchunks = args.cpu_chunks
+        first = (total // 2 // args.chunk) * args.chunk            # a slab from the middle of the grid
+        npts = min(nchunks * args.chunk, total - first)
+        flat = np.arange(first, first + npts, dtype=np.int64)
+        pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
+        c0 = time.perf_counter()
+        with torch.no_grad():
+            want = [ref.query(pts[:, :, s:s + args.chunk], calib)[0, 0] for s in range(0, npts, args.chunk)]
+        cpu_s = time.perf_counter() - c0
+        want = torch.cat(want).numpy()
+        log(f'cpu baseline done: {cpu_s:.1f} s')
+        got = field[first:first + npts].cpu().numpy()
+        out['cpu_baseline'] = {
+            'value': round(npts / cpu_s / 1e6, 4), 'unit': 'Mqueries/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'{npts} queries ({npts // args.chunk} chunks of {args.chunk}) from the middle of '
+                                      f'the same lattice, torch-CPU oracle (oracle/pifu_oracle.py), {cpu_s:.1f} s',
+        }
+        out['parity_check_max_abs_diff'] = float(np.abs(got - want).max())
+
+    # ---- second half of the metric: end-to-end gen_mesh wall time (single GPU) ---------------------------
+    if world == 1 and not args.no_genmesh and args.features == 'filter':
+        import tempfile
+        from pifuhd_amd import reconstruction as recon
+        with tempfile.TemporaryDirectory() as td:
+            timings = {}
+            try:
+                recon.gen_mesh(128, netMR, dev, data, os.path.join(td, 'warm.obj'))            # warm-up (allocations)
+                log('gen_mesh warm-up done')
+                torch.cuda.synchronize(dev)
+                recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'mesh.obj'), timings=timings)
+                out['gen_mesh'] = {'resolution': args.genmesh_res, 'use_octree': True,
+                                   **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()}}
+            except Exception as e:      # the metric line must still be printed
+                out['gen_mesh'] = {'error': repr(e)}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

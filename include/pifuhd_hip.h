@@ -136,6 +136,12 @@ int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream
 int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
                      float *normals, pifu_stream stream);
 
+/* ---- measurement hook (bench.py / profiles): HIP-event timing of every k_mlp_gemm launch on its own stream --
+ * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms),
+ * number of launches and the ALGORITHMIC FLOPs of those launches (2 * valid points * Cout * Cin). */
+int pifu_profile_enable(pifu_ctx *ctx, int on);
+int pifu_profile_read(pifu_ctx *ctx, double *gemm_ms, int64_t *gemm_launches, double *gemm_flops, int reset);
+
 /* ---- OBJ writer: save_obj_mesh_with_color (mesh_util.py:189-198); host buffers ------------------ */
 int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                    const int32_t *faces, int64_t nfaces);

@@ -309,6 +309,17 @@ def grid_points(resolution: int, calib_inv: np.ndarray, flat_index: np.ndarray |
     return np.matmul(g, calib_inv.T)[:, :3].T
 
 
+def grid_points_rect(res, calib_inv: np.ndarray, flat_index: np.ndarray) -> np.ndarray:
+    """Same as grid_points for a rectangular lattice res[0] x res[1] x res[2] (multi-GPU slabs)."""
+    r0, r1, r2 = (int(r) for r in res)
+    i = flat_index // (r1 * r2)
+    j = (flat_index // r2) % r1
+    k = flat_index % r2
+    g = np.stack([i * (2.0 / r0) + (-1.0), j * (2.0 / r1) + (-1.0), k * (2.0 / r2) + (-1.0),
+                  np.ones_like(i, dtype=np.float64)], 1)
+    return np.matmul(g, calib_inv.T)[:, :3].T
+
+
 def batch_eval(points: np.ndarray, eval_func, num_samples: int) -> np.ndarray:
     """Consecutive chunks of `num_samples` points, remainder last (`mesh_util.py:98-114`)."""
     n = points.shape[1]

@@ -98,6 +98,7 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
     delete ctx;

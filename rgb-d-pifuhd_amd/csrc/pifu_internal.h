@@ -98,6 +98,13 @@ struct pifu_ctx {
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
     float *ident_scale = nullptr, *ident_shift = nullptr;   // device ones / zeros [PIFU_MAX_WIDTH]
+    // optional per-launch timing of the dominant kernel (k_mlp_gemm) with HIP events on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
+    size_t prof_used = 0;                 // events in use
+    double prof_flops = 0.0;              // algorithmic FLOPs of the timed launches
+    double prof_ms_acc = 0.0;             // time already folded in (events recycled)
+    int64_t prof_launches = 0;
 };
 
 int pifu_ensure(DevBuf &b, size_t bytes);   // grow-only hipMalloc (synchronises when it grows)

@@ -647,7 +647,27 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             a.partial = stats ? b.partial[i] : nullptr;
             a.ntm = ntm; a.ntn = l.cout_pad / BN; a.g = g;
             const int nblocks = (int)round_up(ntm, 8) * a.ntn;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ctx->prof_on) {
+                if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                    hipEvent_t a0, a1;
+                    PIFU_HIP(hipEventCreate(&a0));
+                    PIFU_HIP(hipEventCreate(&a1));
+                    ctx->prof_ev.push_back(a0);
+                    ctx->prof_ev.push_back(a1);
+                }
+                e0 = ctx->prof_ev[ctx->prof_used];
+                e1 = ctx->prof_ev[ctx->prof_used + 1];
+                ctx->prof_used += 2;
+                PIFU_HIP(hipEventRecord(e0, st));
+            }
             hipLaunchKernelGGL(k_mlp_gemm, dim3(nblocks), dim3(256), 0, st, a);
+            if (ctx->prof_on) {
+                PIFU_HIP(hipEventRecord(e1, st));
+                const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
+                ctx->prof_flops += 2.0 * valid * l.cout * (double)(l.cin_prev + l.cin_feat);
+                ctx->prof_launches += 1;
+            }
             if (stats) {
                 const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                 const int cpg = l.cout / groups;
@@ -801,5 +821,32 @@ int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *
     hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)pred4, n, normals);
     PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+extern "C" int pifu_profile_enable(pifu_ctx *ctx, int on)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_profile_enable: null context");
+    ctx->prof_on = on != 0;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_profile_read(pifu_ctx *ctx, double *gemm_ms, int64_t *gemm_launches, double *gemm_flops, int reset)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_profile_read: null context");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    PIFU_HIP(hipDeviceSynchronize());
+    double ms = ctx->prof_ms_acc;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        float t = 0.f;
+        PIFU_HIP(hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        ms += t;
+    }
+    ctx->prof_ms_acc = ms;
+    ctx->prof_used = 0;                      // events can be recycled: their time is folded into the accumulator
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_launches) *gemm_launches = ctx->prof_launches;
+    if (gemm_flops) *gemm_flops = ctx->prof_flops;
+    if (reset) { ctx->prof_ms_acc = 0.0; ctx->prof_flops = 0.0; ctx->prof_launches = 0; }
     return PIFU_OK;
 }

@@ -1,0 +1,116 @@
+"""Multi-GPU sharding of the grid evaluation: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm; "gloo" in the CPU tests).
+
+The reference has no multi-device code.  What shards is the list of evaluation points of one grid /
+octree level, and - because the MLP's GroupNorm couples all points of one `query()` call (SURVEY C-1) -
+it shards at CHUNK granularity: rank r evaluates a contiguous range of whole chunks of the C-ordered
+list, then ONE all-gather of the fp32 predictions rebuilds the full list on every rank (the only
+exchange step of the path; everything else - octree masks, fills, marching cubes - is recomputed or
+consumed redundantly from the replicated field).  Contiguous chunk ranges of a dense grid are slabs
+along array axis 0 (the "Z-slab" of the north star).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+
+def world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_chunks(total_points: int, chunk: int, world_size: int, rank: int):
+    """Contiguous range of whole chunks for `rank`: returns (first_point, n_points, chunks_per_rank).
+    Every rank gets `chunks_per_rank` chunks except the tail (possibly fewer or none)."""
+    n_chunks = (total_points + chunk - 1) // chunk
+    per = (n_chunks + world_size - 1) // world_size
+    c0 = min(rank * per, n_chunks)
+    c1 = min(c0 + per, n_chunks)
+    first = c0 * chunk
+    last = min(c1 * chunk, total_points)
+    return first, max(last - first, 0), per
+
+
+def sharded_eval(total_points: int, chunk: int, eval_fn, device, group=None):
+    """Evaluate `total_points` list entries in chunk-granular shards and all-gather the predictions.
+
+    eval_fn(first, count) -> float32 tensor [count] on `device` (predictions of list entries
+    first .. first+count, chunks cut relative to `first`).  Returns the float32 tensor [total_points],
+    identical on every rank."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return eval_fn(0, total_points)
+    first, count, per = shard_chunks(total_points, chunk, ws, rank)
+    slot = per * chunk
+    local = torch.zeros(slot, device=device, dtype=torch.float32)
+    if count > 0:
+        local[:count] = eval_fn(first, count)
+    full = torch.empty(ws * slot, device=device, dtype=torch.float32)
+    dist.all_gather_into_tensor(full, local, group=group)
+    return full[:total_points]
+
+
+def eval_lattice_sharded(net, calib_tensor, res, chunk, flags=0, group=None):
+    """Dense lattice res[0] x res[1] x res[2] evaluated across all ranks; returns fp32 [prod(res)]."""
+    from . import _lib
+    from .nets import _ptr, _stream_ptr
+    ctx = net._ctx
+    dev = ctx.device
+    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
+    calib_inv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    res_a = (C.c_int32 * 3)(*[int(r) for r in res])
+    total = int(res[0]) * int(res[1]) * int(res[2])
+
+    def eval_fn(first, count):
+        out = torch.empty(count, device=dev, dtype=torch.float32)
+        _lib.call('pifu_eval_lattice', ctx.h, res_a, calib_inv.ctypes.data_as(C.c_void_p),
+                  calib.ctypes.data_as(C.c_void_p), None, first, count, int(chunk), flags, _ptr(out), _stream_ptr(dev))
+        return out
+    return sharded_eval(total, int(chunk), eval_fn, dev, group)
+
+
+def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, threshold=0.05, flags=0, group=None):
+    """`eval_grid_octree` (`mesh_util.py:124-187`) with every level's network evaluations sharded by
+    whole chunks across ranks and all-gathered; the bookkeeping kernels run redundantly on every rank, so
+    all ranks end with the identical float64 SDF.  Returns (sdf [R,R,R] float64 device tensor, evaluated)."""
+    from . import _lib
+    from .nets import _ptr, _stream_ptr
+    ctx = net._ctx
+    dev = ctx.device
+    st = _stream_ptr(dev)
+    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
+    calib_inv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    res_a = (C.c_int32 * 3)(R, R, R)
+    sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
+    notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8)
+    _lib.call('pifu_octree_begin', ctx.h, R, _ptr(sdf), _ptr(notproc), st)
+    reso = R // init_resolution
+    evaluated = 0
+    while reso > 0:
+        cnt = C.c_int64(0)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st)
+        n = cnt.value
+        idx = torch.empty(max(n, 1), device=dev, dtype=torch.int64)
+        vals = None
+        if n:
+            _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
+
+            def eval_fn(first, count):
+                out = torch.empty(count, device=dev, dtype=torch.float32)
+                _lib.call('pifu_eval_lattice', ctx.h, res_a, calib_inv.ctypes.data_as(C.c_void_p),
+                          calib.ctypes.data_as(C.c_void_p), _ptr(idx), first, count, int(chunk), flags, _ptr(out), st)
+                return out
+            vals = sharded_eval(n, int(chunk), eval_fn, dev, group).contiguous()
+            evaluated += n
+        _lib.call('pifu_octree_commit', ctx.h, R, reso, float(threshold), _ptr(idx), _ptr(vals), n, _ptr(sdf),
+                  _ptr(notproc), st)
+        if reso <= 1:
+            break
+        reso //= 2
+    return sdf, evaluated

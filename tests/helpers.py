@@ -42,3 +42,14 @@ def noisy_field(points):
     v = 1.0 / (1.0 + np.exp(-(0.35 - r) / 0.05))
     v = v + 0.02 * np.sin(37.0 * p[0] + 11.0 * p[1]) * np.cos(23.0 * p[2])
     return v.astype(np.float32)
+
+
+def mlp_only_nets(seed=3, mlp_std=0.16):
+    """Options + a state dict holding only the two SurfaceClassifier MLPs (fast to generate); enough for
+    query() when the feature maps are installed directly."""
+    oc = config.coarse_opt()
+    of = config.fine_opt(oc)
+    spec = {}
+    synth.mlp_keys('netG.mlp', oc.mlp_dim, oc.mlp_res_layers, oc.mlp_norm, spec)
+    synth.mlp_keys('mlp', of.mlp_dim, of.mlp_res_layers, of.mlp_norm, spec)
+    return synth.name_seeded_state_dict(spec, seed=seed, mlp_std=mlp_std, perturb=True), oc, of

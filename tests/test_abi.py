@@ -1,0 +1,65 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/pifuhd_hip.h declares."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'rgb-d-pifuhd_amd', 'csrc'), '-j4'])
+    return _lib
+
+
+def test_header_symbols_exported_and_bound(lib):
+    header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
+    declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header))
+    declared -= {'pifu_ctx', 'pifu_stream'}
+    assert len(declared) >= 20
+    handle = lib.load()
+    for name in sorted(declared):
+        assert hasattr(handle, name), f'{name} declared in the header but not exported'
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    assert handle.pifu_abi_version() == 1
+
+
+def test_no_cpu_fallback(lib):
+    """The product path refuses to run without a GPU instead of silently computing elsewhere."""
+    import torch
+    from pifuhd_amd import config, nets
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(Exception):
+        nets.PIFuNetwNML(config.coarse_opt(), 'orthogonal', 'cuda')
+    with pytest.raises(lib.PifuError):
+        nets.PIFuNetwNML(config.coarse_opt(), 'orthogonal', 'cpu')
+
+
+def test_product_never_imports_oracle():
+    """No file of the product package imports, loads or links anything under oracle/."""
+    pkg = os.path.join(ROOT, 'rgb-d-pifuhd_amd')
+    pat = re.compile(r'(^\s*(from|import)\s+oracle\b)|libmc_oracle|oracle/|pifu_oracle', re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.h', 'Makefile')):
+                text = open(os.path.join(dirpath, f), errors='replace').read()
+                assert not pat.search(text), f'{f} references the oracle'
+
+
+def test_obj_writer_host_only(lib, tmp_path):
+    """pifu_write_obj is host-only code: byte-identical to the reference's format string."""
+    import numpy as np
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util
+    rs = np.random.RandomState(0)
+    v, c = rs.randn(50, 3), rs.rand(50, 3)
+    f = rs.randint(0, 50, size=(80, 3)).astype(np.int32)
+    p = tmp_path / 'a.obj'
+    mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
+    assert p.read_text() == O.obj_text(v, f, c)

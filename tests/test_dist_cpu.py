@@ -1,0 +1,96 @@
+"""Chunk-granular sharding + all-gather (pifuhd_amd/dist.py) on CPU with the gloo backend, world size 2.
+The evaluation function is the CPU oracle: a sharded run must reproduce the single-process result exactly,
+because every rank evaluates whole chunks (GroupNorm couples a chunk)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_chunks_cover_and_align():
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.dist import shard_chunks
+    for total, chunk, ws in [(12345, 500, 2), (5000, 5000, 4), (4999, 5000, 8), (262144, 5000, 8), (7, 3, 5), (0, 10, 2)]:
+        covered = []
+        for r in range(ws):
+            first, cnt, per = shard_chunks(total, chunk, ws, r)
+            assert first % chunk == 0 or cnt == 0            # chunk boundaries = reference chunk boundaries
+            assert cnt <= per * chunk
+            covered.extend(range(first, first + cnt))
+        assert covered == list(range(total))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, total, chunk, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    torch.set_num_threads(2)
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.dist import sharded_eval
+    from helpers import calib_tensor, mlp_only_nets, seeded_features, seeded_points
+    from oracle import pifu_oracle as O
+    sd, oc, of = mlp_only_nets()
+    nets = O.OracleNets(sd, oc, of)
+    nets.feat_coarse, nets.feat_fine = seeded_features(7)
+    pts = seeded_points(21, total, lim=1.0)
+    calib = calib_tensor()
+
+    def eval_fn(first, count):
+        out = []
+        with torch.no_grad():
+            for s in range(first, first + count, chunk):
+                e = min(s + chunk, first + count)
+                out.append(nets.query(pts[:, :, s:e], calib)[0, 0])
+        return torch.cat(out)
+    full = sharded_eval(total, chunk, eval_fn, torch.device('cpu'))
+    if rank == 0:
+        q.put(full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_eval_gloo_world2_matches_single_process():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import calib_tensor, mlp_only_nets, seeded_features, seeded_points
+    from oracle import pifu_oracle as O
+    total, chunk = 1700, 300           # 6 chunks (last ragged): rank 0 gets 3, rank 1 gets 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=500)
+    for p in procs:
+        p.join(timeout=100)
+        assert p.exitcode == 0
+    sd, oc, of = mlp_only_nets()
+    nets = O.OracleNets(sd, oc, of)
+    nets.feat_coarse, nets.feat_fine = seeded_features(7)
+    pts = seeded_points(21, total, lim=1.0)
+    with torch.no_grad():
+        want = torch.cat([nets.query(pts[:, :, s:s + chunk], calib_tensor())[0, 0] for s in range(0, total, chunk)]).numpy()
+    # same chunk membership => same statistics; only the CPU thread count (2 vs all) perturbs the last ulp
+    assert np.abs(got - want).max() < 5e-6
+    # and NOT the result of ignoring chunk boundaries
+    with torch.no_grad():
+        whole = nets.query(pts, calib_tensor())[0, 0].numpy()
+    assert np.abs(whole - want).max() > 1e-4
