@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--res', type=int, default=256, help='lattice points per axis per GPU slab')
     ap.add_argument('--chunk', type=int, default=5000)
     ap.add_argument('--cpu-chunks', type=int, default=200, help='chunks of the workload timed on the CPU oracle')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time bound of the CPU baseline sample')
+    ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-genmesh', action='store_true')
     ap.add_argument('--genmesh-res', type=int, default=512)
@@ -87,7 +89,10 @@ def main():
     torch.cuda.synchronize(dev)
     log(f'feature maps ready ({args.features})')
     calib = data['calib']
+    # synthetic checkpoint only: centre the 0.5 level set inside the volume (30 % of a 64^3 lattice inside)
+    bias_shift = synth.calibrate_occupancy_bias(netMR, calib, sd, 0.3)
     torch.cuda.synchronize(dev)
+    log(f'occupancy bias calibrated (shift {bias_shift:+.3f})')
 
     R = args.res
     res = (world * R, R, R)
@@ -168,27 +173,38 @@ def main():
     # ---- parity spot check + CPU baseline (oracle = checker; never the thing measured as `value`) -----
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pifu_oracle as O
-        torch.set_num_threads(os.cpu_count() or 1)
+        # torch-CPU scales badly past a few dozen threads on these small per-chunk GEMMs (a 256-thread run
+        # of this oracle is >10x slower than a 32-thread one), so the baseline uses at most 32 threads and
+        # says so in `cores`; the sample is bounded by wall time (~args.cpu_seconds), not by a chunk count.
+        ncores = min(os.cpu_count() or 1, args.cpu_threads)
+        torch.set_num_threads(ncores)
         ref = O.OracleNets(sd, oc, of, fine_training=True)
         ref.feat_coarse = netG.im_feat_list[-1].cpu()
         ref.feat_fine = netMR.im_feat_list[-1].cpu()
         calib_inv = np.linalg.inv(calib[0].numpy().astype(np.float64))
-        nchunks = args.cpu_chunks
         first = (total // 2 // args.chunk) * args.chunk            # a slab from the middle of the grid
-        npts = min(nchunks * args.chunk, total - first)
-        flat = np.arange(first, first + npts, dtype=np.int64)
-        pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
-        c0 = time.perf_counter()
+        want = []
+        npts = 0
+        cpu_s = 0.0
         with torch.no_grad():
-            want = [ref.query(pts[:, :, s:s + args.chunk], calib)[0, 0] for s in range(0, npts, args.chunk)]
-        cpu_s = time.perf_counter() - c0
+            while npts < args.cpu_chunks * args.chunk and first + npts < total:
+                n_c = min(args.chunk, total - first - npts)
+                flat = np.arange(first + npts, first + npts + n_c, dtype=np.int64)
+                pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
+                c0 = time.perf_counter()
+                want.append(ref.query(pts, calib)[0, 0])
+                cpu_s += time.perf_counter() - c0
+                npts += n_c
+                if cpu_s > args.cpu_seconds and npts >= 2 * args.chunk:
+                    break
         want = torch.cat(want).numpy()
-        log(f'cpu baseline done: {cpu_s:.1f} s')
+        log(f'cpu baseline done: {npts} queries in {cpu_s:.1f} s on {ncores} threads')
         got = field[first:first + npts].cpu().numpy()
         out['cpu_baseline'] = {
-            'value': round(npts / cpu_s / 1e6, 4), 'unit': 'Mqueries/s', 'cores': torch.get_num_threads(),
+            'value': round(npts / cpu_s / 1e6, 4), 'unit': 'Mqueries/s', 'cores': ncores,
             'kind': 'port', 'sample': f'{npts} queries ({npts // args.chunk} chunks of {args.chunk}) from the middle of '
-                                      f'the same lattice, torch-CPU oracle (oracle/pifu_oracle.py), {cpu_s:.1f} s',
+                                      f'the same lattice, torch-CPU oracle (oracle/pifu_oracle.py), {cpu_s:.1f} s, '
+                                      f'{ncores} of {os.cpu_count()} host threads',
         }
         out['parity_check_max_abs_diff'] = float(np.abs(got - want).max())
 

@@ -240,3 +240,21 @@ def synthetic_inputs(load_size: int = 1024, channels: int = 3, seed: int = 0) ->
         'calib': calib.unsqueeze(0),
         'b_min': [-1, -1, -1], 'b_max': [1, 1, 1],
     }
+
+
+def calibrate_occupancy_bias(net, calib_tensor, state_dict, frac_inside: float = 0.3, resolution: int = 64) -> float:
+    """Random weights rarely put the 0.5 level set inside the volume.  For synthetic checkpoints only:
+    shift the bias of the fine MLP's last layer so that `frac_inside` of a dense `resolution`^3 lattice is
+    predicted inside (the shift does not touch any other activation: the layer is followed by the sigmoid
+    only).  Updates `state_dict` in place, reloads the fine MLP and returns the shift."""
+    from . import mesh_util
+    sdf, _ = mesh_util.eval_grid_device(net, calib_tensor, resolution, 5000, use_octree=False)
+    p = sdf.reshape(-1).clamp(1e-7, 1 - 1e-7)
+    logit = torch.log(p / (1 - p))
+    shift = -float(torch.quantile(logit.float()[::7], 1.0 - frac_inside))
+    last = len(net.opt.mlp_dim) - 2
+    key = f'mlp.filters.{last}.bias'
+    state_dict[key] = state_dict[key] + shift
+    net._sd[key] = net._sd[key] + shift
+    net._push_weights()
+    return shift
