@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -55,6 +56,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
     PIFU_HIP(hipSetDevice(device));
     pifu_ctx *c = new pifu_ctx();
     c->device = device;
+    if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         pifu_set_error("pinned host allocation failed");
@@ -71,7 +73,17 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
             return PIFU_ERR_HIP;
         }
     }
+    if (c->gemm_variant == 9) { (void)hipMalloc(&c->debug_buf, (64 * 40 * 4 + 16384 * 16) * 8); (void)hipMemset(c->debug_buf, 0, (64 * 40 * 4 + 16384 * 16) * 8); }
     *out = c;
+    return PIFU_OK;
+}
+
+// diagnostics only (not part of the public ABI): copy the stamp buffer of the SCHED == 2 build to the host
+extern "C" int pifu_debug_read(pifu_ctx *ctx, void *host, size_t bytes)
+{
+    if (!ctx || !ctx->debug_buf) return PIFU_ERR_STATE;
+    PIFU_HIP(hipDeviceSynchronize());
+    PIFU_HIP(hipMemcpy(host, ctx->debug_buf, bytes, hipMemcpyDeviceToHost));
     return PIFU_OK;
 }
 

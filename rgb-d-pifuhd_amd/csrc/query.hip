@@ -28,8 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BM = PIFU_BM, BN = PIFU_BN, BK = PIFU_BK;
-constexpr int LDS_LD = BK + 4;           // 36 floats = 144 B row stride: conflict-free ds_read_b128
-constexpr int TILE_FLOATS = BM * LDS_LD; // one operand tile in LDS
 
 struct Seg {
     const float *ptr;     // [rows][ld]
@@ -59,6 +57,7 @@ struct GemmArgs {
     float2 *partial;  // [ntm][ldy] (sum, sum of squares) over the valid rows of the tile, or null
     int ntm, ntn;
     ChunkGeom g;
+    unsigned long long *stamps;   // diagnostic builds only (SCHED == 2): [64 blocks][40 steps][4]
 };
 
 __device__ __forceinline__ int chunk_len(const ChunkGeom &g, int c) { return c == g.nchunks - 1 ? g.last_len : g.chunk; }
@@ -67,10 +66,19 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 
 // ------------------------------------------------------------------------------------------------
 // k_mlp_gemm:  Y[rows][Cout] = act(A)[rows][K] * W^T + bias,  A = concatenation of <= 3 segments.
+// Template: TBK = K step (16 or 32), SCHED = 0 (staging after the step's MFMAs) or 1 (staging of the next
+// tile interleaved between the MFMA groups of the current one, so a wave has no MFMA-free phase).
 // ------------------------------------------------------------------------------------------------
+template <int TBK, int SCHED>
 __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // [buf][A|B] = 73,728 B
+    constexpr int LD = TBK + 4;              // row stride (floats): 144 B / 80 B, conflict-free ds_read_b128
+    constexpr int TILE = BM * LD;            // one operand tile
+    constexpr int F4_PER_ROW = TBK / 4;      // float4 columns per tile row
+    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    constexpr int NP = BM / ROWS_PER_PASS;   // staging passes per operand (4 at BK 32, 2 at BK 16)
+    constexpr int NS = TBK / 8;              // MFMA groups of 8 k per step
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // [buf][A|B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -85,20 +93,20 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
     const size_t row0 = (size_t)tile_m * BM;
     const int col0 = tile_n * BN;
 
-    const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
+    const int kq = tid % F4_PER_ROW, sr = tid / F4_PER_ROW;   // staging: float4 column kq of rows sr + p * ROWS_PER_PASS
     const int b1 = a.seg[0].width;
     const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
-    const int nsteps = a.ldw / BK;
+    const int nsteps = a.ldw / TBK;
 
-    // One K step of both operands in flight in registers (issued before the MFMAs of the current step,
-    // transformed and written to the other LDS buffer after them).  The per-segment choices are selected
-    // with scalar selects so the staging code is branch-free: raw segments use scale 1 / shift 0 / slope 1.
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
+    // One K step of both operands in flight in registers.  The per-segment choices are made with scalar
+    // selects so the staging code is branch-free: raw segments use scale 1 / shift 0 / slope 1.
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;      // (named registers: arrays here end up in scratch)
+    ra2 = ra3 = rw2 = rw3 = make_float4(0, 0, 0, 0);
     float rslope = 1.f;
 
 #define PIFU_GLOAD(step_)                                                                                  \
     {                                                                                                      \
-        const int kk = (step_) * BK;                                                                       \
+        const int kk = (step_) * TBK;                                                                      \
         const int sg = (kk >= b1) + (kk >= b2);                                                            \
         const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
         const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
@@ -110,76 +118,147 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
         const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
         const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
         ra0 = *reinterpret_cast<const float4 *>(ap);                                                       \
-        ra1 = *reinterpret_cast<const float4 *>(ap + (size_t)32 * ld);                                     \
-        ra2 = *reinterpret_cast<const float4 *>(ap + (size_t)64 * ld);                                     \
-        ra3 = *reinterpret_cast<const float4 *>(ap + (size_t)96 * ld);                                     \
+        ra1 = *reinterpret_cast<const float4 *>(ap + (size_t)ROWS_PER_PASS * ld);                          \
+        if constexpr (NP > 2) {                                                                            \
+            ra2 = *reinterpret_cast<const float4 *>(ap + (size_t)2 * ROWS_PER_PASS * ld);                  \
+            ra3 = *reinterpret_cast<const float4 *>(ap + (size_t)3 * ROWS_PER_PASS * ld);                  \
+        }                                                                                                  \
         rsc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                         \
         rsh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                         \
         const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                                 \
         rw0 = *reinterpret_cast<const float4 *>(wp);                                                       \
-        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)32 * a.ldw);                                  \
-        rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)64 * a.ldw);                                  \
-        rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)96 * a.ldw);                                  \
+        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)ROWS_PER_PASS * a.ldw);                       \
+        if constexpr (NP > 2) {                                                                            \
+            rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)2 * ROWS_PER_PASS * a.ldw);               \
+            rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)3 * ROWS_PER_PASS * a.ldw);               \
+        }                                                                                                  \
     }
 
-#define PIFU_XFORM(v_)                                                                                     \
+#define PIFU_STORE1(buf_, p_, va_, vw_)                                                                    \
     {                                                                                                      \
+        float *la = lds + (buf_) * 2 * TILE + (sr + (p_) * ROWS_PER_PASS) * LD + kq * 4;                   \
         float t_;                                                                                          \
-        t_ = fmaf(v_.x, rsc.x, rsh.x); v_.x = fmaxf(t_, rslope * t_);                                      \
-        t_ = fmaf(v_.y, rsc.y, rsh.y); v_.y = fmaxf(t_, rslope * t_);                                      \
-        t_ = fmaf(v_.z, rsc.z, rsh.z); v_.z = fmaxf(t_, rslope * t_);                                      \
-        t_ = fmaf(v_.w, rsc.w, rsh.w); v_.w = fmaxf(t_, rslope * t_);                                      \
+        t_ = fmaf(va_.x, rsc.x, rsh.x); va_.x = fmaxf(t_, rslope * t_);                                    \
+        t_ = fmaf(va_.y, rsc.y, rsh.y); va_.y = fmaxf(t_, rslope * t_);                                    \
+        t_ = fmaf(va_.z, rsc.z, rsh.z); va_.z = fmaxf(t_, rslope * t_);                                    \
+        t_ = fmaf(va_.w, rsc.w, rsh.w); va_.w = fmaxf(t_, rslope * t_);                                    \
+        *reinterpret_cast<float4 *>(la) = va_;                                                             \
+        *reinterpret_cast<float4 *>(la + TILE) = vw_;                                                      \
     }
-
-#define PIFU_LSTORE(buf_)                                                                                  \
+    // first / second half of the staging passes
+#define PIFU_LSTORE_H0(buf_)                                                                               \
     {                                                                                                      \
-        float *la = lds + (buf_) * 2 * TILE_FLOATS + sr * LDS_LD + kq * 4;                                 \
-        float *lb = la + TILE_FLOATS;                                                                      \
-        PIFU_XFORM(ra0) PIFU_XFORM(ra1) PIFU_XFORM(ra2) PIFU_XFORM(ra3)                                    \
-        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
-        *reinterpret_cast<float4 *>(la + 32 * LDS_LD) = ra1;                                               \
-        *reinterpret_cast<float4 *>(la + 64 * LDS_LD) = ra2;                                               \
-        *reinterpret_cast<float4 *>(la + 96 * LDS_LD) = ra3;                                               \
-        *reinterpret_cast<float4 *>(lb) = rw0;                                                             \
-        *reinterpret_cast<float4 *>(lb + 32 * LDS_LD) = rw1;                                               \
-        *reinterpret_cast<float4 *>(lb + 64 * LDS_LD) = rw2;                                               \
-        *reinterpret_cast<float4 *>(lb + 96 * LDS_LD) = rw3;                                               \
+        PIFU_STORE1(buf_, 0, ra0, rw0)                                                                     \
+        if constexpr (NP > 2) PIFU_STORE1(buf_, 1, ra1, rw1)                                               \
+    }
+#define PIFU_LSTORE_H1(buf_)                                                                               \
+    {                                                                                                      \
+        if constexpr (NP > 2) {                                                                            \
+            PIFU_STORE1(buf_, 2, ra2, rw2)                                                                 \
+            PIFU_STORE1(buf_, 3, ra3, rw3)                                                                 \
+        } else {                                                                                           \
+            PIFU_STORE1(buf_, 1, ra1, rw1)                                                                 \
+        }                                                                                                  \
     }
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    // lane (i = lane & 31, h = lane >> 5) reads k = 8 s + 4 h + t, t = 0..3, for both operands
+    auto mfma_group = [&](const float *A, const float *B, int s) __attribute__((always_inline)) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+        const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
+        const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
+        const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+        }
+    };
 
+    unsigned long long t_begin = 0;
+    if (SCHED == 2) t_begin = __builtin_amdgcn_s_memtime();
     PIFU_GLOAD(0)
-    PIFU_LSTORE(0)
+    PIFU_LSTORE_H0(0)
+    PIFU_LSTORE_H1(0)
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
         const bool more = step + 1 < nsteps;
         if (more) PIFU_GLOAD(step + 1)
-
-        // lane (i = lane & 31, h = lane >> 5) reads k = 8 s + 4 h + t, t = 0..3, for both operands
-        const float *A = lds + buf * 2 * TILE_FLOATS + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-        const float *B = lds + buf * 2 * TILE_FLOATS + TILE_FLOATS + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        if (SCHED == 0) {
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LDS_LD + s * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
-            const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LDS_LD + s * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
+            if (more) {
+                PIFU_LSTORE_H0(buf ^ 1)
+                PIFU_LSTORE_H1(buf ^ 1)
             }
+        } else if (SCHED == 3) {     // non-MFMA section (staging, barrier, next loads) at raised priority
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
+            __builtin_amdgcn_s_setprio(3);
+            if (more) {
+                PIFU_LSTORE_H0(buf ^ 1)
+                PIFU_LSTORE_H1(buf ^ 1)
+            }
+        } else if (SCHED == 4) {     // MFMA phase at raised priority
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
+            __builtin_amdgcn_s_setprio(0);
+            if (more) {
+                PIFU_LSTORE_H0(buf ^ 1)
+                PIFU_LSTORE_H1(buf ^ 1)
+            }
+        } else if (SCHED == 2) {     // diagnostic: s_memtime stamps of one wave per block (never the product path)
+            const bool rec = a.stamps && blockIdx.x < 64 && step < 40 && tid == 0;
+            unsigned long long t0, t1, t2;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                PIFU_LSTORE_H0(buf ^ 1)
+                PIFU_LSTORE_H1(buf ^ 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (rec) {
+                unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 40 + step) * 4;
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+            }
+        } else {
+            // the other LDS buffer is free during the whole step (its readers finished before the last
+            // barrier), so the next tile is written in two halves between this step's MFMA groups
+            constexpr int H = NS / 2;
+#pragma unroll
+            for (int s = 0; s < H; ++s) mfma_group(A, B, s);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) PIFU_LSTORE_H0(buf ^ 1)
+#pragma unroll
+            for (int s = H; s < NS - (NS > 2 ? 1 : 0); ++s) mfma_group(A, B, s);
+            if (more) PIFU_LSTORE_H1(buf ^ 1)
+            if (NS > 2) mfma_group(A, B, NS - 1);
         }
-        if (more) PIFU_LSTORE(buf ^ 1)
         __syncthreads();
     }
 
+    if (SCHED == 2 && a.stamps && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long *o = a.stamps + 64 * 40 * 4 + ((size_t)blockIdx.x * 4 + wave) * 4;
+        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_getreg(63492); o[3] = __builtin_amdgcn_s_getreg(63508);
+    }
     // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
     const int h = lane >> 5, j = lane & 31;
     const int local0 = (tile_m % a.g.tpc) * BM;
@@ -661,7 +740,16 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 ctx->prof_used += 2;
                 PIFU_HIP(hipEventRecord(e0, st));
             }
-            hipLaunchKernelGGL(k_mlp_gemm, dim3(nblocks), dim3(256), 0, st, a);
+            switch (ctx->gemm_variant) {
+            case 1: hipLaunchKernelGGL((k_mlp_gemm<32, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((k_mlp_gemm<16, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((k_mlp_gemm<16, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((k_mlp_gemm<32, 3>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 9: a.stamps = (L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr; hipLaunchKernelGGL((k_mlp_gemm<32, 2>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 0: hipLaunchKernelGGL((k_mlp_gemm<32, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;   // MFMA phase at raised priority (+2 %)
+            }
             if (ctx->prof_on) {
                 PIFU_HIP(hipEventRecord(e1, st));
                 const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;

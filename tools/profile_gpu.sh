@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 passes for profiles/: (1) kernel trace + stats of the bench command, (2)+(3) PMC passes (HBM bytes).
+# Counters are collected in their own runs (no trace domains besides --kernel-trace), as the pool requires.
+set -x
+export TMPDIR=/tmp
+OUT=gpurun_out/prof
+mkdir -p $OUT
+BENCH="bench.py --steps 2 --warmup 1 --features synthetic --no-cpu-baseline --no-genmesh"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
+SMALL="bench.py --steps 1 --warmup 0 --res 128 --features synthetic --no-cpu-baseline --no-genmesh"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $SMALL > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $SMALL > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $SMALL > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err
+find $OUT -name "*.csv" | head -30
+du -sh $OUT
