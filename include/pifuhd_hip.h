@@ -83,6 +83,26 @@ int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);
 int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, int H, int W,
                       pifu_stream stream);
 
+/* ---- image encoders: filter() / filter_global() / filter_local() -------------------------------------------
+ * Parameters are registered by their reference state-dict names (HOST fp32 arrays): coarse net keys without the
+ * `netG.` prefix (`image_filter.*`, `netF.*`, `netB.*`), fine net keys as `fine.image_filter.*`.
+ * norm: 0 = BatchNorm2d with running statistics (eval), 1 = BatchNorm2d with batch statistics (the fine level
+ * under recon(): SURVEY C-2), 2 = GroupNorm(32, C) (Filter.py:37-46).
+ * pifu_filter_coarse = PIFuNetwNML.filter (PIFuNetwNML.py:73-97): img device NCHW [1][Cimg][H][W]; runs netF / netB
+ * (networks.py:131-207) when enabled and writes their NCHW [1][3][H][W] outputs, then the HGFilter
+ * (Filter.py:186-228) on cat[img, nmlF, nmlB]; the LAST stack's output becomes the coarse query feature map and is
+ * optionally exported as NCHW [1][hg_dim][H/4][W/4] (ave_pool) to feat_nchw.
+ * pifu_filter_fine = PIFuMRNet.filter_local (PIFuMRNet.py:83-118, rect = None): normals (NCHW, Hn x Wn) are
+ * resized bilinearly (align_corners) to H x W, concatenated, HGFilter('no_down'); output [1][hg_dim][H/2][W/2]. */
+int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
+int pifu_enc_clear(pifu_ctx *ctx);
+int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
+                       int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
+                       float *feat_nchw, pifu_stream stream);
+int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF,
+                     const float *nmlB, int Hn, int Wn, int num_stack, int hg_depth, int hg_dim, int norm,
+                     float *feat_nchw, pifu_stream stream);
+
 /* ---- query: PIFuMRNet.query / PIFuNetwNML.query (PIFuMRNet.py:119-186, PIFuNetwNML.py:99-141) - */
 /* points: device fp32 [3][n] (the reference's [1,3,N] tensor); calib: HOST fp32 4x4 row-major;
  * `chunk` = number of points the reference would pass per query() call (GroupNorm couples the points

@@ -42,6 +42,10 @@ SIGNATURES = {
     'pifu_mlp_set_layer': (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'pifu_set_depth_normalizer': (_i32, [_p, _f, _f]),
     'pifu_set_features': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
+    'pifu_enc_set_param': (_i32, [_p, C.c_char_p, _p, _p, _i32]),
+    'pifu_enc_clear': (_i32, [_p]),
+    'pifu_filter_coarse': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'pifu_filter_fine': (_i32, [_p, _p, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'pifu_query': (_i32, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
     'pifu_eval_lattice': (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _p]),
     'pifu_octree_begin': (_i32, [_p, _i32, _p, _p, _p]),

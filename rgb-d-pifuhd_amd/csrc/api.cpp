@@ -97,9 +97,12 @@ static void free_layer(MlpLayer &l)
     l.set = false;
 }
 
+extern "C" int pifu_enc_clear(pifu_ctx *ctx);
+
 extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
 {
     if (!ctx) return PIFU_OK;
+    (void)pifu_enc_clear(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (int L = 0; L < 2; ++L) {

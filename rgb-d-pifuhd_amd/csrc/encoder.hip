@@ -1,0 +1,967 @@
+// Image encoders of the hot path on gfx950: the stacked-hourglass HGFilter (Filter.py:23-228) and the
+// pix2pixHD GlobalGenerator normal nets (networks.py:131-207), i.e. PIFuNetwNML.filter
+// (PIFuNetwNML.py:73-97) and PIFuMRNet.filter_local (PIFuMRNet.py:83-118).
+//
+// Layout: every activation is NHWC fp32 ([pixel][channel], channel stride `ld` so that a tensor can be a
+// channel slice of a wider buffer: the ConvBlock concat is written in place).  A convolution is an
+// implicit GEMM: rows = output pixels, K = taps x input channels (channels padded to the 32-wide K step),
+// columns = output channels; the A tile is gathered tap by tap while it is staged into LDS, with the
+// preceding norm (+ReLU) fused into that staging pass as a per-channel scale/shift (the pre-activation
+// ConvBlock is conv(relu(norm(x)))), zero / reflection padding applied AFTER the activation.  Same exact-
+// fp32 MFMA core (v_mfma_f32_32x32x2_f32, 128x128x32 tile, 4 waves x 64x64) as the MLP GEMM.  Statistics
+// for train-mode BatchNorm / InstanceNorm / GroupNorm come from a separate per-channel reduction pass
+// (deterministic, double accumulation across blocks).
+#include "pifu_internal.h"
+
+#include <math.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD = BK + 4;
+constexpr int TILE = BM * LD;
+
+struct ConvArgs {
+    const float *X;         // input NHWC
+    int Hin, Win, ldx;
+    int cin;                // channels per tap, multiple of 32 (input buffers are padded accordingly)
+    const float *scale;     // per-channel prologue (ones / zeros / slope 1 for a raw input)
+    const float *shift;
+    float slope;            // 0 = ReLU, 1 = identity
+    int RW;                 // logical row grid width (rows = RH * RW)
+    int nrows;
+    int os, oy0, ox0;       // output pixel = (ry * os + oy0, rx * os + ox0)
+    int Wout;
+    int is;                 // input step: input pixel of tap t = (ry * is + dy_t, rx * is + dx_t)
+    int ntaps;
+    const short2 *taps;     // (dy, dx) per tap, device
+    int reflect;            // 1 = reflection padding, 0 = zeros
+    const float *W;         // [cout_pad][ntaps * cin]
+    const float *bias;      // [cout_pad] (zeros if the conv has no bias)
+    float *Y;               // output NHWC (already offset to the first output channel of this conv)
+    int ldy;
+    const float *R;         // optional residual added in the epilogue (same pixel indexing as Y)
+    int ldr;
+    int cout;               // valid output channels
+    int ntm, ntn;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
+    const int kq = tid & 7, sr = tid >> 3;
+    const int ldw = a.ntaps * a.cin;
+    const int nsteps = ldw / BK;
+
+    // the 4 rows this thread stages: logical (ry, rx) -> input base pixel
+    int by0, bx0, by1, bx1, by2, bx2, by3, bx3;
+    bool v0, v1, v2, v3;
+    {
+        int r;
+        r = row0 + sr;      v0 = r < a.nrows; by0 = (r / a.RW) * a.is; bx0 = (r % a.RW) * a.is;
+        r = row0 + sr + 32; v1 = r < a.nrows; by1 = (r / a.RW) * a.is; bx1 = (r % a.RW) * a.is;
+        r = row0 + sr + 64; v2 = r < a.nrows; by2 = (r / a.RW) * a.is; bx2 = (r % a.RW) * a.is;
+        r = row0 + sr + 96; v3 = r < a.nrows; by3 = (r / a.RW) * a.is; bx3 = (r % a.RW) * a.is;
+    }
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
+    bool m0, m1, m2, m3;
+
+#define CONV_SRC(by_, bx_, vrow_, dst_, msk_)                                                          \
+    {                                                                                                  \
+        int iy = (by_) + tp.x, ix = (bx_) + tp.y;                                                      \
+        if (a.reflect) {                                                                               \
+            iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * (a.Hin - 1) - iy : iy);                             \
+            ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * (a.Win - 1) - ix : ix);                             \
+        }                                                                                              \
+        msk_ = (vrow_) && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;                              \
+        dst_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+        if (msk_) dst_ = *reinterpret_cast<const float4 *>(a.X + ((size_t)iy * a.Win + ix) * a.ldx + cc); \
+    }
+#define CONV_GLOAD(step_)                                                                              \
+    {                                                                                                  \
+        const int kk = (step_) * BK;                                                                   \
+        const int t = kk / a.cin;                                                                      \
+        const int cc = kk - t * a.cin + kq * 4;                                                        \
+        const short2 tp = a.taps[t];                                                                   \
+        CONV_SRC(by0, bx0, v0, ra0, m0) CONV_SRC(by1, bx1, v1, ra1, m1)                                \
+        CONV_SRC(by2, bx2, v2, ra2, m2) CONV_SRC(by3, bx3, v3, ra3, m3)                                \
+        rsc = *reinterpret_cast<const float4 *>(a.scale + cc);                                         \
+        rsh = *reinterpret_cast<const float4 *>(a.shift + cc);                                         \
+        const float *wp = a.W + (size_t)(col0 + sr) * ldw + kk + kq * 4;                               \
+        rw0 = *reinterpret_cast<const float4 *>(wp);                                                   \
+        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)32 * ldw);                                \
+        rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)64 * ldw);                                \
+        rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)96 * ldw);                                \
+    }
+#define CONV_XF(v_, m_)                                                                                \
+    {                                                                                                  \
+        float t_;                                                                                      \
+        t_ = fmaf(v_.x, rsc.x, rsh.x); v_.x = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
+        t_ = fmaf(v_.y, rsc.y, rsh.y); v_.y = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
+        t_ = fmaf(v_.z, rsc.z, rsh.z); v_.z = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
+        t_ = fmaf(v_.w, rsc.w, rsh.w); v_.w = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
+    }
+#define CONV_LSTORE(buf_)                                                                              \
+    {                                                                                                  \
+        float *la = lds + (buf_) * 2 * TILE + sr * LD + kq * 4;                                        \
+        float *lb = la + TILE;                                                                         \
+        CONV_XF(ra0, m0) CONV_XF(ra1, m1) CONV_XF(ra2, m2) CONV_XF(ra3, m3)                            \
+        *reinterpret_cast<float4 *>(la) = ra0;                                                         \
+        *reinterpret_cast<float4 *>(la + 32 * LD) = ra1;                                               \
+        *reinterpret_cast<float4 *>(la + 64 * LD) = ra2;                                               \
+        *reinterpret_cast<float4 *>(la + 96 * LD) = ra3;                                               \
+        *reinterpret_cast<float4 *>(lb) = rw0;                                                         \
+        *reinterpret_cast<float4 *>(lb + 32 * LD) = rw1;                                               \
+        *reinterpret_cast<float4 *>(lb + 64 * LD) = rw2;                                               \
+        *reinterpret_cast<float4 *>(lb + 96 * LD) = rw3;                                               \
+    }
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    CONV_GLOAD(0)
+    CONV_LSTORE(0)
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) CONV_GLOAD(step + 1)
+        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) CONV_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = col0 + wn * 64 + nt * 32 + j;
+        const bool cok = col < a.cout;
+        const float bias = cok ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (cok && row < a.nrows) {
+                    const int ry = row / a.RW, rx = row - ry * a.RW;
+                    const size_t pix = (size_t)(ry * a.os + a.oy0) * a.Wout + (rx * a.os + a.ox0);
+                    float v = acc[r] + bias;
+                    if (a.R) v += a.R[pix * a.ldr + col];
+                    a.Y[pix * a.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- per-channel statistics of an NHWC tensor: partial (sum, sum^2) per block of rows -----------------
+__global__ void k_channel_stats(const float *X, int ld, int C, int P, int rows_per_block, double *partial /* [nb][C][2] */)
+{
+    __shared__ double sh[256 * 2];
+    const int cg = C / 4;                     // float4 channel groups
+    const int tpr = blockDim.x / cg > 0 ? blockDim.x / cg : 1;   // threads along rows
+    const int c4 = threadIdx.x % cg, tr = threadIdx.x / cg;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(P, r0 + rows_per_block);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < tpr && c4 < cg) {
+        for (int r = r0 + tr; r < r1; r += tpr) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)r * ld + c4 * 4);
+            s[0] += v.x; q[0] = fmaf(v.x, v.x, q[0]);
+            s[1] += v.y; q[1] = fmaf(v.y, v.y, q[1]);
+            s[2] += v.z; q[2] = fmaf(v.z, v.z, q[2]);
+            s[3] += v.w; q[3] = fmaf(v.w, v.w, q[3]);
+        }
+    }
+    // reduce over tr in a fixed order through LDS, one channel component at a time
+    for (int k = 0; k < 4; ++k) {
+        __syncthreads();
+        sh[threadIdx.x * 2] = s[k];
+        sh[threadIdx.x * 2 + 1] = q[k];
+        __syncthreads();
+        if (tr == 0 && c4 < cg) {
+            double ds = 0, dq = 0;
+            for (int t = 0; t < tpr; ++t) { ds += sh[(t * cg + c4) * 2]; dq += sh[(t * cg + c4) * 2 + 1]; }
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2] = ds;
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2 + 1] = dq;
+        }
+    }
+}
+
+// one wave per group: (sum, sum^2) over blocks and the group's channels -> per-channel scale / shift
+__global__ void k_stats_finalize(const double *partial, int nb, int C, int cpg, int groups, double count_per_channel,
+                                 const float *gamma, const float *beta, float eps, float *scale, float *shift)
+{
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= groups) return;
+    double s = 0, q = 0;
+    const int total = nb * cpg;
+    for (int i = lane; i < total; i += 64) {
+        const int b = i / cpg, ch = wid * cpg + i % cpg;
+        s += partial[((size_t)b * C + ch) * 2];
+        q += partial[((size_t)b * C + ch) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    const double cnt = count_per_channel * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var > 0 ? var : 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int i = lane; i < cpg; i += 64) {
+        const int ch = wid * cpg + i;
+        const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
+        scale[ch] = (float)(g * rstd);
+        shift[ch] = (float)(b - mean * rstd * g);
+    }
+}
+
+// ---- element-wise helpers (NHWC, float4 over channels) ------------------------------------------------
+// out = a + (b * scale + shift)   (scale == null: plain add)
+__global__ void k_add(const float *A, int lda, const float *B, int ldb, const float *scale, const float *shift,
+                      float *O, int ldo, int C, size_t P)
+{
+    const int cg = C / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * cg) return;
+    const size_t p = i / cg;
+    const int c = (int)(i % cg) * 4;
+    const float4 a = *reinterpret_cast<const float4 *>(A + p * lda + c);
+    float4 b = *reinterpret_cast<const float4 *>(B + p * ldb + c);
+    if (scale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+        b.x = fmaf(b.x, sc.x, sh.x); b.y = fmaf(b.y, sc.y, sh.y); b.z = fmaf(b.z, sc.z, sh.z); b.w = fmaf(b.w, sc.w, sh.w);
+    }
+    *reinterpret_cast<float4 *>(O + p * ldo + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// out = act(x * scale + shift), act(t) = max(t, slope * t)
+__global__ void k_affine_act(const float *X, int ldx, const float *scale, const float *shift, float slope, float *O, int ldo,
+                             int C, size_t P)
+{
+    const int cg = C / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * cg) return;
+    const size_t p = i / cg;
+    const int c = (int)(i % cg) * 4;
+    float4 v = *reinterpret_cast<const float4 *>(X + p * ldx + c);
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+    float t;
+    t = fmaf(v.x, sc.x, sh.x); v.x = fmaxf(t, slope * t);
+    t = fmaf(v.y, sc.y, sh.y); v.y = fmaxf(t, slope * t);
+    t = fmaf(v.z, sc.z, sh.z); v.z = fmaxf(t, slope * t);
+    t = fmaf(v.w, sc.w, sh.w); v.w = fmaxf(t, slope * t);
+    *reinterpret_cast<float4 *>(O + p * ldo + c) = v;
+}
+
+// avg_pool2d(x, 2, stride 2)  (Filter.py:113,191)
+__global__ void k_avgpool2(const float *X, int ldx, int Win, float *O, int ldo, int C, int Ho, int Wo)
+{
+    const int cg = C / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Ho * Wo * cg) return;
+    const int c = (int)(i % cg) * 4;
+    const size_t p = i / cg;
+    const int ox = (int)(p % Wo), oy = (int)(p / Wo);
+    const float *s = X + ((size_t)(2 * oy) * Win + 2 * ox) * ldx + c;
+    const float4 a = *reinterpret_cast<const float4 *>(s), b = *reinterpret_cast<const float4 *>(s + ldx);
+    const float4 d = *reinterpret_cast<const float4 *>(s + (size_t)Win * ldx), e = *reinterpret_cast<const float4 *>(s + (size_t)Win * ldx + ldx);
+    *reinterpret_cast<float4 *>(O + p * ldo + c) =
+        make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
+                    (a.w + b.w + d.w + e.w) * 0.25f);
+}
+
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4])
+{
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = (1.f - t) + 1.f;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+// out = up1 + bicubic_x2(low), align_corners=True (Filter.py:125-127)
+__global__ void k_bicubic_up2_add(const float *L, int ldl, int h, int w, const float *U, int ldu, float *O, int ldo, int C)
+{
+    const int cg = C / 4, H = 2 * h, Wd = 2 * w;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * Wd * cg) return;
+    const int c = (int)(i % cg) * 4;
+    const size_t p = i / cg;
+    const int ox = (int)(p % Wd), oy = (int)(p / Wd);
+    const float sy = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = w > 1 ? (float)(w - 1) / (float)(Wd - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_coeffs(fy - iy, wy);
+    cubic_coeffs(fx - ix, wx);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), h - 1);
+        float4 row = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(ix - 1 + b, 0), w - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(L + ((size_t)yy * w + xx) * ldl + c);
+            row.x = fmaf(v.x, wx[b], row.x); row.y = fmaf(v.y, wx[b], row.y);
+            row.z = fmaf(v.z, wx[b], row.z); row.w = fmaf(v.w, wx[b], row.w);
+        }
+        acc.x = fmaf(row.x, wy[a], acc.x); acc.y = fmaf(row.y, wy[a], acc.y);
+        acc.z = fmaf(row.z, wy[a], acc.z); acc.w = fmaf(row.w, wy[a], acc.w);
+    }
+    const float4 u = *reinterpret_cast<const float4 *>(U + p * ldu + c);
+    *reinterpret_cast<float4 *>(O + p * ldo + c) = make_float4(u.x + acc.x, u.y + acc.y, u.z + acc.z, u.w + acc.w);
+}
+
+// Build the 32-channel NHWC network input [img (Cimg) | nmlF (3) | nmlB (3) | 0...] at H x W from an NCHW
+// image and NCHW normal maps at (Hn x Wn), bilinear align_corners=True if the sizes differ
+// (PIFuNetwNML.py:84-92, PIFuMRNet.py:99-103).
+__global__ void k_pack_input(const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn,
+                             float *O, int ldo)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    const int x = (int)(p % W), y = (int)(p / W);
+    float *o = O + p * ldo;
+    int c = 0;
+    for (int k = 0; k < Cimg; ++k) o[c++] = img[(size_t)k * H * W + p];
+    const float *srcs[2] = {nF, nB};
+    for (int s = 0; s < 2; ++s) {
+        if (!srcs[s]) continue;
+        if (Hn == H && Wn == W) {
+            for (int k = 0; k < 3; ++k) o[c++] = srcs[s][(size_t)k * H * W + p];
+        } else {
+            const float fy = Hn > 1 ? (float)y * ((float)(Hn - 1) / (float)(H - 1)) : 0.f;
+            const float fx = Wn > 1 ? (float)x * ((float)(Wn - 1) / (float)(W - 1)) : 0.f;
+            const int y0 = min((int)fy, Hn - 1), x0 = min((int)fx, Wn - 1);
+            const int y1 = min(y0 + 1, Hn - 1), x1 = min(x0 + 1, Wn - 1);
+            const float ly = fy - y0, lx = fx - x0;
+            for (int k = 0; k < 3; ++k) {
+                const float *m = srcs[s] + (size_t)k * Hn * Wn;
+                const float v = (1.f - ly) * ((1.f - lx) * m[(size_t)y0 * Wn + x0] + lx * m[(size_t)y0 * Wn + x1]) +
+                                ly * ((1.f - lx) * m[(size_t)y1 * Wn + x0] + lx * m[(size_t)y1 * Wn + x1]);
+                o[c++] = v;
+            }
+        }
+    }
+    for (; c < ldo; ++c) o[c] = 0.f;
+}
+
+// Last layer of the normal nets: ReflectionPad(3) + Conv7x7 (64 -> 3) + Tanh, NCHW output (networks.py:158-160).
+// One thread per output pixel; the input is consumed with its InstanceNorm + ReLU prologue.
+__global__ void k_conv7_to3_tanh(const float *X, int ldx, int H, int W, int Cin, const float *scale, const float *shift,
+                                 const float *Wt /* [3][49][Cin] */, const float *bias, float *out_nchw)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)H * W) return;
+    const int x = (int)(p % W), y = (int)(p / W);
+    float acc[3] = {bias[0], bias[1], bias[2]};
+    for (int dy = -3; dy <= 3; ++dy) {
+        int iy = y + dy;
+        iy = iy < 0 ? -iy : (iy >= H ? 2 * (H - 1) - iy : iy);
+        for (int dx = -3; dx <= 3; ++dx) {
+            int ix = x + dx;
+            ix = ix < 0 ? -ix : (ix >= W ? 2 * (W - 1) - ix : ix);
+            const float *src = X + ((size_t)iy * W + ix) * ldx;
+            const int tap = (dy + 3) * 7 + (dx + 3);
+            for (int c = 0; c < Cin; c += 4) {
+                float4 v = *reinterpret_cast<const float4 *>(src + c);
+                const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float4 w = *reinterpret_cast<const float4 *>(Wt + ((size_t)o * 49 + tap) * Cin + c);
+                    acc[o] = fmaf(v.x, w.x, acc[o]); acc[o] = fmaf(v.y, w.y, acc[o]);
+                    acc[o] = fmaf(v.z, w.z, acc[o]); acc[o] = fmaf(v.w, w.w, acc[o]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) out_nchw[(size_t)o * H * W + p] = tanhf(acc[o]);
+}
+
+__global__ void k_nhwc_to_nchw(const float *src, int ld, int C, int HW, float *dst)
+{
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? src[(size_t)p * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) dst[(size_t)c * HW + p] = tile[tx][r];
+    }
+}
+
+// ======================================================================================================
+// host side: tensors, parameter registry, graph execution
+// ======================================================================================================
+struct Tensor {
+    float *p = nullptr;
+    int H = 0, W = 0, C = 0, ld = 0;
+    size_t pixels() const { return (size_t)H * W; }
+};
+
+struct Affine {           // per-channel transform applied by the consumer
+    const float *scale = nullptr, *shift = nullptr;
+    float slope = 1.f;    // 1 identity, 0 ReLU
+};
+
+struct HostParam {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct EncState {
+    std::map<std::string, HostParam> params;
+    std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
+    DevBuf arena;
+    size_t used = 0;
+    hipStream_t st = nullptr;
+    int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
+    std::string err;
+};
+
+std::map<pifu_ctx *, EncState *> g_states;
+
+EncState &state_of(pifu_ctx *ctx)
+{
+    auto it = g_states.find(ctx);
+    if (it == g_states.end()) it = g_states.emplace(ctx, new EncState()).first;
+    return *it->second;
+}
+
+struct Fail {
+    std::string msg;
+};
+
+float *arena_take(EncState &S, size_t floats)
+{
+    const size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
+    if (S.used + bytes > S.arena.bytes) throw Fail{"encoder arena exhausted"};
+    float *p = reinterpret_cast<float *>(static_cast<char *>(S.arena.p) + S.used);
+    S.used += bytes;
+    return p;
+}
+
+Tensor new_tensor(EncState &S, int H, int W, int C)
+{
+    Tensor t;
+    t.H = H; t.W = W; t.C = C; t.ld = C;
+    t.p = arena_take(S, (size_t)H * W * C);
+    return t;
+}
+
+Tensor slice(const Tensor &t, int c0, int c)
+{
+    Tensor s = t;
+    s.p = t.p + c0;
+    s.C = c;
+    return s;
+}
+
+const HostParam &param(EncState &S, const std::string &name)
+{
+    auto it = S.params.find(name);
+    if (it == S.params.end()) throw Fail{"missing encoder parameter " + name};
+    return it->second;
+}
+
+float *dev_upload(EncState &S, const std::string &key, const std::vector<float> &host)
+{
+    auto it = S.dev.find(key);
+    if (it != S.dev.end()) return it->second;
+    float *d = nullptr;
+    if (hipMalloc(&d, host.size() * sizeof(float)) != hipSuccess) throw Fail{"hipMalloc failed for " + key};
+    if (hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw Fail{"hipMemcpy failed for " + key};
+    S.dev[key] = d;
+    return d;
+}
+
+const float *ones(EncState &S) { return dev_upload(S, "#ones", std::vector<float>(PIFU_MAX_WIDTH, 1.f)); }
+const float *zeros(EncState &S) { return dev_upload(S, "#zeros", std::vector<float>(PIFU_MAX_WIDTH, 0.f)); }
+Affine raw(EncState &S) { return Affine{ones(S), zeros(S), 1.f}; }
+
+inline unsigned nblk(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---- normalisation: returns the per-channel affine that realises `norm(x)`; slope is set by the caller ----
+Affine norm_affine(EncState &S, const std::string &prefix, const Tensor &x, int norm)
+{
+    Affine a;
+    if (norm == 0) {   // BatchNorm2d eval: running statistics, folded once
+        const std::string key = prefix + "#bn_eval";
+        if (!S.dev.count(key + ".s")) {
+            const auto &g = param(S, prefix + ".weight").data, &b = param(S, prefix + ".bias").data;
+            const auto &rm = param(S, prefix + ".running_mean").data, &rv = param(S, prefix + ".running_var").data;
+            std::vector<float> sc(g.size()), sh(g.size());
+            for (size_t i = 0; i < g.size(); ++i) {
+                const double rstd = 1.0 / sqrt((double)rv[i] + 1e-5);
+                sc[i] = (float)(g[i] * rstd);
+                sh[i] = (float)((double)b[i] - (double)rm[i] * rstd * g[i]);
+            }
+            dev_upload(S, key + ".s", sc);
+            dev_upload(S, key + ".b", sh);
+        }
+        a.scale = S.dev[key + ".s"];
+        a.shift = S.dev[key + ".b"];
+        return a;
+    }
+    // batch statistics over H*W (batch 1): BatchNorm train (per channel), GroupNorm (32 groups), InstanceNorm
+    const int C = x.C;
+    const int groups = norm == 2 ? 32 : C;
+    const int cpg = C / groups;
+    const int P = (int)x.pixels();
+    int rows_per_block = 1024;
+    const int nb = (P + rows_per_block - 1) / rows_per_block;
+    double *partial = reinterpret_cast<double *>(arena_take(S, (size_t)nb * C * 2 * 2));
+    const int cg = C / 4;
+    int threads = 256;
+    if (cg > 256) threads = cg <= 512 ? 512 : 1024;
+    if (cg > 1024) throw Fail{"channel count too large for k_channel_stats"};
+    hipLaunchKernelGGL(k_channel_stats, dim3(nb), dim3(threads), 0, S.st, (const float *)x.p, x.ld, C, P, rows_per_block, partial);
+    float *sc = arena_take(S, C), *sh = arena_take(S, C);
+    const float *gamma = nullptr, *beta = nullptr;
+    if (norm != 3) {
+        gamma = dev_upload(S, prefix + ".weight", param(S, prefix + ".weight").data);
+        beta = dev_upload(S, prefix + ".bias", param(S, prefix + ".bias").data);
+    }
+    hipLaunchKernelGGL(k_stats_finalize, dim3(nblk((size_t)groups * 64, 256)), dim3(256), 0, S.st, (const double *)partial, nb, C,
+                       cpg, groups, (double)P, gamma, beta, 1e-5f, sc, sh);
+    a.scale = sc;
+    a.shift = sh;
+    return a;
+}
+
+// ---- convolution launcher -----------------------------------------------------------------------------
+struct ConvGeom {
+    int k = 3, stride = 1, pad = 1;
+    bool reflect = false;
+};
+
+// weights [Cout][Cin][k][k] -> [cout_pad][taps * cin_pad] (tap-major, then channel)
+const float *packed_conv_weight(EncState &S, const std::string &name, int cin_pad, int cout_pad, int *cout, int *k)
+{
+    const HostParam &w = param(S, name);
+    if (w.shape.size() != 4) throw Fail{name + ": expected a 4-d conv weight"};
+    const int co = (int)w.shape[0], ci = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    *cout = co; *k = kh;
+    const std::string key = name + "#pk" + std::to_string(cin_pad) + "_" + std::to_string(cout_pad);
+    if (S.dev.count(key)) return S.dev[key];
+    if (ci > cin_pad) throw Fail{name + ": input channels exceed the padded width"};
+    std::vector<float> pk((size_t)cout_pad * kh * kw * cin_pad, 0.f);
+    for (int o = 0; o < co; ++o)
+        for (int c = 0; c < ci; ++c)
+            for (int t = 0; t < kh * kw; ++t)
+                pk[((size_t)o * kh * kw + t) * cin_pad + c] = w.data[((size_t)o * ci + c) * kh * kw + t];
+    return dev_upload(S, key, pk);
+}
+
+const float *packed_bias(EncState &S, const std::string &name, int cout_pad, bool has_bias)
+{
+    const std::string key = name + "#b" + std::to_string(cout_pad);
+    if (S.dev.count(key)) return S.dev[key];
+    std::vector<float> b(cout_pad, 0.f);
+    if (has_bias) {
+        const auto &src = param(S, name).data;
+        for (size_t i = 0; i < src.size(); ++i) b[i] = src[i];
+    }
+    return dev_upload(S, key, b);
+}
+
+const short2 *taps_for(EncState &S, int k, int pad)
+{
+    const std::string key = "#taps" + std::to_string(k) + "_" + std::to_string(pad);
+    if (!S.dev.count(key)) {
+        std::vector<float> packed(k * k);     // reinterpret as short2
+        short2 *t = reinterpret_cast<short2 *>(packed.data());
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) t[dy * k + dx] = make_short2((short)(dy - pad), (short)(dx - pad));
+        dev_upload(S, key, packed);
+    }
+    return reinterpret_cast<const short2 *>(S.dev[key]);
+}
+
+void launch_conv(EncState &S, ConvArgs a)
+{
+    a.ntm = (a.nrows + BM - 1) / BM;
+    a.ntn = (a.cout + BN - 1) / BN;
+    const int nblocks = (int)round_up(a.ntm, 8) * a.ntn;
+    hipLaunchKernelGGL(k_conv_gemm, dim3(nblocks), dim3(256), 0, S.st, a);
+}
+
+// y (a channel slice of `out`) = conv(act(x)); out must have the conv's output size
+void conv2d(EncState &S, const std::string &wname, const std::string &bname, const Tensor &x, const Affine &act,
+            const ConvGeom &g, Tensor out, const Tensor *residual = nullptr)
+{
+    if (x.ld % 4 || x.C % BK) throw Fail{wname + ": input channels must be padded to 32"};
+    int cout = 0, k = 0;
+    const int cout_pad = (int)round_up(out.C, BN);
+    const float *w = packed_conv_weight(S, wname, x.C, cout_pad, &cout, &k);
+    if (cout != out.C || k != g.k) throw Fail{wname + ": shape mismatch"};
+    ConvArgs a{};
+    a.X = x.p; a.Hin = x.H; a.Win = x.W; a.ldx = x.ld; a.cin = x.C;
+    a.scale = act.scale; a.shift = act.shift; a.slope = act.slope;
+    a.RW = out.W; a.nrows = out.H * out.W; a.os = 1; a.oy0 = 0; a.ox0 = 0; a.Wout = out.W; a.is = g.stride;
+    a.ntaps = g.k * g.k; a.taps = taps_for(S, g.k, g.pad); a.reflect = g.reflect ? 1 : 0;
+    a.W = w; a.bias = packed_bias(S, bname.empty() ? wname + "#nobias" : bname, cout_pad, !bname.empty());
+    a.Y = out.p; a.ldy = out.ld; a.cout = out.C;
+    if (residual) { a.R = residual->p; a.ldr = residual->ld; }
+    launch_conv(S, a);
+}
+
+// ConvTranspose2d(k 3, stride 2, padding 1, output_padding 1) as 4 output-parity classes (networks.py:155-157)
+void conv_transpose2d(EncState &S, const std::string &wname, const std::string &bname, const Tensor &x, const Affine &act,
+                      Tensor out)
+{
+    const HostParam &w = param(S, wname);            // [Cin][Cout][3][3]
+    const int ci = (int)w.shape[0], co = (int)w.shape[1];
+    if (ci != x.C || co != out.C || out.H != 2 * x.H || out.W != 2 * x.W) throw Fail{wname + ": transposed conv shape mismatch"};
+    const int cout_pad = (int)round_up(co, BN);
+    const float *bias = packed_bias(S, bname, cout_pad, true);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            // oy = 2 ry + py;  contributing ky: py == 0 -> {1 (iy = ry)},  py == 1 -> {0 (iy = ry + 1), 2 (iy = ry)}
+            int kys[2], iys[2], nky = 0, kxs[2], ixs[2], nkx = 0;
+            if (py == 0) { kys[nky] = 1; iys[nky++] = 0; } else { kys[nky] = 0; iys[nky++] = 1; kys[nky] = 2; iys[nky++] = 0; }
+            if (px == 0) { kxs[nkx] = 1; ixs[nkx++] = 0; } else { kxs[nkx] = 0; ixs[nkx++] = 1; kxs[nkx] = 2; ixs[nkx++] = 0; }
+            const int ntaps = nky * nkx;
+            const std::string key = wname + "#ct" + std::to_string(py) + std::to_string(px);
+            if (!S.dev.count(key)) {
+                std::vector<float> pk((size_t)cout_pad * ntaps * ci, 0.f), tp(ntaps);
+                short2 *t2 = reinterpret_cast<short2 *>(tp.data());
+                int t = 0;
+                for (int a = 0; a < nky; ++a)
+                    for (int b = 0; b < nkx; ++b, ++t) {
+                        t2[t] = make_short2((short)iys[a], (short)ixs[b]);
+                        for (int o = 0; o < co; ++o)
+                            for (int c = 0; c < ci; ++c)
+                                pk[((size_t)o * ntaps + t) * ci + c] = w.data[(((size_t)c * co + o) * 3 + kys[a]) * 3 + kxs[b]];
+                    }
+                dev_upload(S, key, pk);
+                dev_upload(S, key + ".t", tp);
+            }
+            ConvArgs a{};
+            a.X = x.p; a.Hin = x.H; a.Win = x.W; a.ldx = x.ld; a.cin = x.C;
+            a.scale = act.scale; a.shift = act.shift; a.slope = act.slope;
+            a.RW = x.W; a.nrows = x.H * x.W; a.os = 2; a.oy0 = py; a.ox0 = px; a.Wout = out.W; a.is = 1;
+            a.ntaps = ntaps; a.taps = reinterpret_cast<const short2 *>(S.dev[key + ".t"]); a.reflect = 0;
+            a.W = S.dev[key]; a.bias = bias; a.Y = out.p; a.ldy = out.ld; a.cout = co;
+            launch_conv(S, a);
+        }
+}
+
+// ---- building blocks -------------------------------------------------------------------------------------
+// ConvBlock (Filter.py:23-69): cat[conv1(a(bn1 x)), conv2(a(bn2 o1)), conv3(a(bn3 o2))] + (x | conv1x1(a(bn4 x)))
+Tensor conv_block(EncState &S, const std::string &p, const Tensor &x, int cout)
+{
+    Tensor out = new_tensor(S, x.H, x.W, cout);
+    const ConvGeom g3{3, 1, 1, false}, g1{1, 1, 0, false};
+    Affine a1 = norm_affine(S, p + ".bn1", x, S.norm); a1.slope = 0.f;
+    Tensor o1 = slice(out, 0, cout / 2), o2 = slice(out, cout / 2, cout / 4), o3 = slice(out, cout / 2 + cout / 4, cout / 4);
+    // o2 / o3 are 32..64-channel slices: their inputs must be 32-aligned slices, which holds for all widths used
+    conv2d(S, p + ".conv1.weight", "", x, a1, g3, o1);
+    Affine a2 = norm_affine(S, p + ".bn2", o1, S.norm); a2.slope = 0.f;
+    conv2d(S, p + ".conv2.weight", "", o1, a2, g3, o2);
+    Affine a3 = norm_affine(S, p + ".bn3", o2, S.norm); a3.slope = 0.f;
+    conv2d(S, p + ".conv3.weight", "", o2, a3, g3, o3);
+    if (x.C != cout) {
+        Affine a4 = norm_affine(S, p + ".bn4", x, S.norm); a4.slope = 0.f;
+        conv2d(S, p + ".downsample.2.weight", "", x, a4, g1, out, &out);      // out = conv1x1(...) + cat (in place)
+    } else {
+        hipLaunchKernelGGL(k_add, dim3(nblk(out.pixels() * (cout / 4), 256)), dim3(256), 0, S.st, (const float *)out.p, out.ld,
+                           (const float *)x.p, x.ld, (const float *)nullptr, (const float *)nullptr, out.p, out.ld, cout, out.pixels());
+    }
+    return out;
+}
+
+Tensor avg_pool(EncState &S, const Tensor &x)
+{
+    Tensor o = new_tensor(S, x.H / 2, x.W / 2, x.C);
+    hipLaunchKernelGGL(k_avgpool2, dim3(nblk(o.pixels() * (x.C / 4), 256)), dim3(256), 0, S.st, (const float *)x.p, x.ld, x.W, o.p, o.ld,
+                       x.C, o.H, o.W);
+    return o;
+}
+
+Tensor hourglass(EncState &S, const std::string &p, int level, const Tensor &x)
+{
+    Tensor up1 = conv_block(S, p + ".b1_" + std::to_string(level), x, x.C);
+    Tensor low = conv_block(S, p + ".b2_" + std::to_string(level), avg_pool(S, x), x.C);
+    if (level > 1) low = hourglass(S, p, level - 1, low);
+    else low = conv_block(S, p + ".b2_plus_" + std::to_string(level), low, x.C);
+    low = conv_block(S, p + ".b3_" + std::to_string(level), low, x.C);
+    Tensor out = new_tensor(S, x.H, x.W, x.C);
+    hipLaunchKernelGGL(k_bicubic_up2_add, dim3(nblk(out.pixels() * (x.C / 4), 256)), dim3(256), 0, S.st, (const float *)low.p, low.ld,
+                       low.H, low.W, (const float *)up1.p, up1.ld, out.p, out.ld, x.C);
+    return out;
+}
+
+// Filter.forward (Filter.py:186-228); returns the LAST stack's output (what inference keeps)
+Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_stack, int depth, int last_ch, bool ave_pool)
+{
+    const ConvGeom g1{1, 1, 0, false};
+    const int H1 = (in32.H + 2 * 3 - 7) / 2 + 1, W1 = (in32.W + 2 * 3 - 7) / 2 + 1;
+    Tensor c1 = new_tensor(S, H1, W1, 64);
+    conv2d(S, p + ".conv1.weight", p + ".conv1.bias", in32, raw(S), ConvGeom{7, 2, 3, false}, c1);
+    // x = relu(bn1(conv1)) is both normalised again (ConvBlock.bn1/bn4) and used by the shortcut: materialise it
+    Affine b1 = norm_affine(S, p + ".bn1", c1, S.norm);
+    Tensor x = new_tensor(S, H1, W1, 64);
+    hipLaunchKernelGGL(k_affine_act, dim3(nblk(x.pixels() * 16, 256)), dim3(256), 0, S.st, (const float *)c1.p, c1.ld, b1.scale, b1.shift,
+                       0.f, x.p, x.ld, 64, x.pixels());
+    x = conv_block(S, p + ".conv2", x, 128);
+    if (ave_pool) x = avg_pool(S, x);
+    x = conv_block(S, p + ".conv3", x, 128);
+    x = conv_block(S, p + ".conv4", x, 256);
+    Tensor prev = x, out;
+    for (int s = 0; s < n_stack; ++s) {
+        const std::string ss = std::to_string(s);
+        Tensor ll = hourglass(S, p + ".m" + ss, depth, prev);
+        ll = conv_block(S, p + ".top_m_" + ss, ll, 256);
+        Tensor cl = new_tensor(S, ll.H, ll.W, 256);
+        conv2d(S, p + ".conv_last" + ss + ".weight", p + ".conv_last" + ss + ".bias", ll, raw(S), g1, cl);
+        Affine be = norm_affine(S, p + ".bn_end" + ss, cl, S.norm); be.slope = 0.f;        // relu(bn_end(.)) as a prologue
+        const int lc_pad = (int)round_up(last_ch, BK);
+        out = new_tensor(S, ll.H, ll.W, lc_pad);                                             // padded so that `al` can read it
+        if (lc_pad != last_ch) (void)hipMemsetAsync(out.p, 0, out.pixels() * lc_pad * sizeof(float), S.st);
+        Tensor out_valid = out; out_valid.C = last_ch;
+        conv2d(S, p + ".l" + ss + ".weight", p + ".l" + ss + ".bias", cl, be, g1, out_valid);
+        if (s < n_stack - 1) {
+            Tensor t1 = new_tensor(S, ll.H, ll.W, 256), t2 = new_tensor(S, ll.H, ll.W, 256);
+            conv2d(S, p + ".bl" + ss + ".weight", p + ".bl" + ss + ".bias", cl, be, g1, t1, &prev);   // previous + bl(ll)
+            conv2d(S, p + ".al" + ss + ".weight", p + ".al" + ss + ".bias", out, raw(S), g1, t2, &t1); // + al(out)
+            prev = t2;
+        }
+    }
+    out.C = last_ch;
+    return out;
+}
+
+// GlobalGenerator (networks.py:131-207) with InstanceNorm(affine=False); returns NCHW [3][H][W] in `dst`
+void global_generator(EncState &S, const std::string &p, const Tensor &in32, float *dst_nchw)
+{
+    const int inst = 3;
+    Tensor x = new_tensor(S, in32.H, in32.W, 64);
+    conv2d(S, p + ".model.1.weight", p + ".model.1.bias", in32, raw(S), ConvGeom{7, 1, 3, true}, x);
+    Affine act = norm_affine(S, "", x, inst); act.slope = 0.f;
+    int idx = 4, c = 64;
+    for (int i = 0; i < 4; ++i) {
+        Tensor y = new_tensor(S, x.H / 2, x.W / 2, 2 * c);
+        const std::string m = p + ".model." + std::to_string(idx);
+        conv2d(S, m + ".weight", m + ".bias", x, act, ConvGeom{3, 2, 1, false}, y);
+        act = norm_affine(S, "", y, inst); act.slope = 0.f;
+        x = y; c *= 2; idx += 3;
+    }
+    // the first ResnetBlock consumes relu(IN(x)) as its RAW input and as the residual: materialise it
+    Tensor r = new_tensor(S, x.H, x.W, c);
+    hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.st, (const float *)x.p, x.ld, act.scale,
+                       act.shift, 0.f, r.p, r.ld, c, r.pixels());
+    const ConvGeom gr{3, 1, 1, true};
+    for (int b = 0; b < 9; ++b) {
+        const std::string q = p + ".model." + std::to_string(idx) + ".conv_block";
+        Tensor h1 = new_tensor(S, r.H, r.W, c), h2 = new_tensor(S, r.H, r.W, c), o = new_tensor(S, r.H, r.W, c);
+        conv2d(S, q + ".1.weight", q + ".1.bias", r, raw(S), gr, h1);
+        Affine a1 = norm_affine(S, "", h1, inst); a1.slope = 0.f;
+        conv2d(S, q + ".5.weight", q + ".5.bias", h1, a1, gr, h2);
+        Affine a2 = norm_affine(S, "", h2, inst);
+        hipLaunchKernelGGL(k_add, dim3(nblk(o.pixels() * (c / 4), 256)), dim3(256), 0, S.st, (const float *)r.p, r.ld, (const float *)h2.p,
+                           h2.ld, a2.scale, a2.shift, o.p, o.ld, c, o.pixels());          // x + IN(conv(...))
+        r = o; idx += 1;
+    }
+    x = r;
+    act = raw(S);
+    for (int i = 0; i < 4; ++i) {
+        Tensor y = new_tensor(S, x.H * 2, x.W * 2, c / 2);
+        const std::string m = p + ".model." + std::to_string(idx);
+        conv_transpose2d(S, m + ".weight", m + ".bias", x, act, y);
+        act = norm_affine(S, "", y, inst); act.slope = 0.f;
+        x = y; c /= 2; idx += 3;
+    }
+    // ReflectionPad(3) + Conv7x7 (64 -> 3) + Tanh
+    const std::string m = p + ".model." + std::to_string(idx + 1);
+    const HostParam &w = param(S, m + ".weight");
+    const std::string key = m + "#w7";
+    if (!S.dev.count(key)) {
+        const int ci = (int)w.shape[1];
+        std::vector<float> pk((size_t)3 * 49 * ci);
+        for (int o = 0; o < 3; ++o)
+            for (int cc = 0; cc < ci; ++cc)
+                for (int t = 0; t < 49; ++t) pk[((size_t)o * 49 + t) * ci + cc] = w.data[((size_t)o * ci + cc) * 49 + t];
+        dev_upload(S, key, pk);
+    }
+    const float *bias = dev_upload(S, m + ".bias", param(S, m + ".bias").data);
+    hipLaunchKernelGGL(k_conv7_to3_tanh, dim3(nblk(x.pixels(), 128)), dim3(128), 0, S.st, (const float *)x.p, x.ld, x.H, x.W, x.C, act.scale,
+                       act.shift, (const float *)S.dev[key], bias, dst_nchw);
+}
+
+Tensor pack_input(EncState &S, const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn)
+{
+    Tensor t = new_tensor(S, H, W, 32);
+    if (Cimg + (nF ? 3 : 0) + (nB ? 3 : 0) > 32) throw Fail{"more than 32 input channels"};
+    hipLaunchKernelGGL(k_pack_input, dim3(nblk(t.pixels(), 256)), dim3(256), 0, S.st, img, Cimg, H, W, nF, nB, Hn, Wn, t.p, t.ld);
+    return t;
+}
+
+int begin(pifu_ctx *ctx, EncState &S, size_t arena_bytes, hipStream_t st)
+{
+    PIFU_HIP(hipSetDevice(ctx->device));
+    int rc = pifu_ensure(S.arena, arena_bytes);
+    if (rc) return rc;
+    S.used = 0;
+    S.st = st;
+    return PIFU_OK;
+}
+
+}  // namespace
+
+extern "C" int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host, const int64_t *shape, int rank)
+{
+    PIFU_REQUIRE(ctx && name && host && shape && rank >= 0 && rank <= 4, PIFU_ERR_INVALID, "pifu_enc_set_param: bad argument");
+    EncState &S = state_of(ctx);
+    HostParam hp;
+    size_t n = 1;
+    for (int i = 0; i < rank; ++i) { hp.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    hp.data.assign(host, host + n);
+    S.params[name] = std::move(hp);
+    // drop every packed copy derived from this parameter
+    const std::string nm(name);
+    for (auto it = S.dev.begin(); it != S.dev.end();) {
+        if (it->first.compare(0, nm.size(), nm) == 0) { (void)hipFree(it->second); it = S.dev.erase(it); }
+        else ++it;
+    }
+    return PIFU_OK;
+}
+
+extern "C" int pifu_enc_clear(pifu_ctx *ctx)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_enc_clear: null context");
+    auto it = g_states.find(ctx);
+    if (it == g_states.end()) return PIFU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : it->second->dev) (void)hipFree(kv.second);
+    if (it->second->arena.p) (void)hipFree(it->second->arena.p);
+    delete it->second;
+    g_states.erase(it);
+    return PIFU_OK;
+}
+
+// PIFuNetwNML.filter (PIFuNetwNML.py:73-97)
+extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
+                                  int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
+                                  float *feat_nchw, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && img_nchw, PIFU_ERR_INVALID, "pifu_filter_coarse: null argument");
+    PIFU_REQUIRE(H % 16 == 0 && W % 16 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_coarse: H, W must be multiples of 16");
+    PIFU_REQUIRE((!use_front || nmlF) && (!use_back || nmlB), PIFU_ERR_INVALID, "pifu_filter_coarse: normal-map output buffers missing");
+    PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_coarse: bad norm / hg_dim");
+    EncState &S = state_of(ctx);
+    const size_t px = (size_t)H * W;
+    int rc = begin(ctx, S, px * 4 * (size_t)(2600 + 700 * num_stack) + ((size_t)64 << 20), (hipStream_t)stream);
+    if (rc) return rc;
+    try {
+        if (use_front || use_back) {
+            Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W);
+            if (use_front) { const size_t mark = S.used; global_generator(S, "netF", in, nmlF); S.used = mark; }
+            if (use_back) { const size_t mark = S.used; global_generator(S, "netB", in, nmlB); S.used = mark; }
+            S.used = 0;   // stream order keeps the reuse safe
+        }
+        Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W);
+        S.norm = norm;
+        Tensor f = hg_filter(S, "image_filter", in, num_stack, hg_depth, hg_dim, ave_pool != 0);
+        // install as the coarse query feature map (NHWC) and optionally export NCHW
+        FeatMap &fm = ctx->feat[0];
+        const size_t bytes = f.pixels() * f.C * sizeof(float);
+        if (bytes > fm.bytes) {
+            if (fm.nhwc) PIFU_HIP(hipFree(fm.nhwc));
+            fm.nhwc = nullptr;
+            PIFU_HIP(hipMalloc(&fm.nhwc, bytes));
+            fm.bytes = bytes;
+        }
+        fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
+        PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
+                                  hipMemcpyDeviceToDevice, S.st));
+        if (feat_nchw)
+            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)f.p, f.ld, f.C,
+                               (int)f.pixels(), feat_nchw);
+    } catch (const Fail &e) {
+        pifu_set_error("pifu_filter_coarse: %s", e.msg.c_str());
+        return PIFU_ERR_STATE;
+    }
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+// PIFuMRNet.filter_local (PIFuMRNet.py:83-118), rect = None
+extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF, const float *nmlB,
+                                int Hn, int Wn, int num_stack, int hg_depth, int hg_dim, int norm, float *feat_nchw,
+                                pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && img_nchw, PIFU_ERR_INVALID, "pifu_filter_fine: null argument");
+    PIFU_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_fine: H, W must be multiples of 8");
+    PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_fine: bad norm / hg_dim");
+    EncState &S = state_of(ctx);
+    const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
+    int rc = begin(ctx, S, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)64 << 20), (hipStream_t)stream);
+    if (rc) return rc;
+    try {
+        Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
+        S.norm = norm;
+        Tensor f = hg_filter(S, "fine.image_filter", in, num_stack, hg_depth, hg_dim, false);
+        FeatMap &fm = ctx->feat[1];
+        const size_t bytes = f.pixels() * f.C * sizeof(float);
+        if (bytes > fm.bytes) {
+            if (fm.nhwc) PIFU_HIP(hipFree(fm.nhwc));
+            fm.nhwc = nullptr;
+            PIFU_HIP(hipMalloc(&fm.nhwc, bytes));
+            fm.bytes = bytes;
+        }
+        fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
+        PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
+                                  hipMemcpyDeviceToDevice, S.st));
+        if (feat_nchw)
+            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)f.p, f.ld, f.C,
+                               (int)f.pixels(), feat_nchw);
+    } catch (const Fail &e) {
+        pifu_set_error("pifu_filter_fine: %s", e.msg.c_str());
+        return PIFU_ERR_STATE;
+    }
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}

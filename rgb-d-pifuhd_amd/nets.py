@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, encoder
+from . import _lib
 
 _NORM_CODE = {'group': _lib.NORM_GROUP}
 
@@ -84,6 +84,21 @@ def _push_mlp(ctx, level, sd, prefix, dims, res_layers, merge_layer, norm_code):
                 rv, rvp = _host_f32(sd[f'{prefix}.norms.{i}.running_var'])
         keep.append((w, b, g, be, rm, rv))
         _lib.call('pifu_mlp_set_layer', ctx.h, level, i, wp, bp, gp, bep, rmp, rvp)
+
+
+_ENC_NORM = {('batch', False): 0, ('batch', True): 1, ('group', False): 2, ('group', True): 2}
+
+
+def _push_encoder_params(ctx, sd, prefix):
+    """Register every floating-point parameter / buffer of an encoder with the context (HOST fp32 copies)."""
+    for key, t in sd.items():
+        if not (key.startswith('image_filter.') or key.startswith('netF.') or key.startswith('netB.')):
+            continue
+        if not t.dtype.is_floating_point:
+            continue
+        a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+        shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+        _lib.call('pifu_enc_set_param', ctx.h, (prefix + key).encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
 
 
 class BasePIFuNet:
@@ -163,6 +178,7 @@ class PIFuNetwNML(BasePIFuNet):
         _push_mlp(self._ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers),
                   int(o.merge_layer), code)
         _lib.call('pifu_set_depth_normalizer', self._ctx.h, float(o.loadSize // 2), float(o.z_size))
+        _push_encoder_params(self._ctx, self._sd, '')
 
     def train(self, mode=True):
         changed = mode != self.training
@@ -176,11 +192,27 @@ class PIFuNetwNML(BasePIFuNet):
         """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`)."""
         if self._sd is None:
             raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter()')
-        images = images.to(self.device, torch.float32)
-        feats, self.normx, self.nmlF, self.nmlB = encoder.filter_coarse(self._sd, self.opt, images,
-                                                                        bn_training=self.training)
-        self.im_feat_list = feats if self.training else [feats[-1]]
-        self._set_features(self.im_feat_list[-1])
+        images = images.to(self.device, torch.float32).contiguous()
+        if images.dim() != 4 or images.shape[0] != 1:
+            raise NotImplementedError('images [1,C,H,W] (batch size 1, the reconstruction path)')
+        if self.training:
+            raise NotImplementedError('coarse-level filter() in train mode (all stacks, train-mode norms) is a training-'
+                                      'time path; recon() always calls netG.eval() first (reconstruction.py:288-289)')
+        o = self.opt
+        _, cimg, h, w = images.shape
+        if o.hg_down != 'ave_pool':
+            if o.hg_down == 'no_down':
+                raise NotImplementedError("coarse level with hg_down='no_down'")
+            raise NameError('unknown downsampling type')                       # Filter.py:197
+        use_f, use_b = self.netF is not None, self.netB is not None
+        self.nmlF = torch.empty(1, 3, h, w, device=self.device) if use_f else None
+        self.nmlB = torch.empty(1, 3, h, w, device=self.device) if use_b else None
+        feat = torch.empty(1, o.hg_dim, h // 4, w // 4, device=self.device)
+        _lib.call('pifu_filter_coarse', self._ctx.h, _ptr(images), cimg, h, w, int(o.num_stack), int(o.hg_depth),
+                  int(o.hg_dim), _ENC_NORM[(o.norm, False)], 1, int(use_f), int(use_b), _ptr(self.nmlF), _ptr(self.nmlB),
+                  _ptr(feat), _stream_ptr(self.device))
+        self.im_feat_list = [feat]          # eval mode keeps the last stack only (PIFuNetwNML.py:96-97)
+        self.normx = None                   # never read on the reconstruction path
 
     def _set_features(self, feat):
         feat = feat.contiguous()
@@ -262,6 +294,7 @@ class PIFuMRNet(BasePIFuNet):
         o = self.opt
         code = _mlp_norm_code(o.mlp_norm, self.training)      # train mode => per-chunk batch statistics (C-2)
         _push_mlp(self._ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
+        _push_encoder_params(self._ctx, self._sd, 'fine.')
 
     # -- filter ------------------------------------------------------------------------------------
     def filter_global(self, images):
@@ -277,10 +310,25 @@ class PIFuMRNet(BasePIFuNet):
         images = images.to(self.device, torch.float32)
         if images.dim() != 5 or images.shape[0] != 1 or images.shape[1] != 1:
             raise NotImplementedError('images [1,1,C,H,W] (single view, the reconstruction path)')
-        feats, self.normx = encoder.filter_fine(self._sd, self.opt, self.netG.opt, images[:, 0], self.netG.nmlF,
-                                                self.netG.nmlB, bn_training=self.training)
-        self.im_feat_list = feats if self.training else [feats[-1]]
-        self._set_features(self.im_feat_list[-1])
+        x = images[0].contiguous()
+        _, cimg, h, w = x.shape
+        o, g = self.opt, self.netG
+        use_f = bool(getattr(g.opt, 'use_front_normal', False))
+        use_b = bool(getattr(g.opt, 'use_back_normal', False))
+        if (use_f and g.nmlF is None) or (use_b and g.nmlB is None):
+            raise _lib.PifuError(_lib.ERR_STATE, 'filter_global() must precede filter_local()')
+        big = int(o.loadSizeBig) if (use_f or use_b) else h
+        if (use_f or use_b) and (h != big or w != big):
+            raise ValueError(f'image size {h}x{w} does not match loadSizeBig {big} (torch.cat would fail in the reference)')
+        hn, wn = (g.nmlF if use_f else g.nmlB).shape[2:] if (use_f or use_b) else (h, w)
+        feat = torch.empty(1, o.hg_dim, h // 2, w // 2, device=self.device)
+        _lib.call('pifu_filter_fine', self._ctx.h, _ptr(x), cimg, h, w, _ptr(g.nmlF) if use_f else None,
+                  _ptr(g.nmlB) if use_b else None, int(hn), int(wn), int(o.num_stack), int(o.hg_depth), int(o.hg_dim),
+                  _ENC_NORM[(o.norm, bool(self.training))], _ptr(feat), _stream_ptr(self.device))
+        if self.training and o.num_stack > 1:
+            raise NotImplementedError('train-mode multi-stack outputs are a training-time path')
+        self.im_feat_list = [feat]
+        self.normx = None
 
     def _set_features(self, feat):
         feat = feat.contiguous()

@@ -1,0 +1,82 @@
+"""HIP encoders (HGFilter + pix2pixHD normal nets as implicit-GEMM MFMA convolutions) vs the golden vectors
+generated from the reference (tests/golden/filter_small.npz, filter_full_sub.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+
+
+def test_filter_tiny_matches_reference(golden_dir):
+    """64x64 coarse image / 128x128 fine image, perturbed parameters; the fine level runs its BatchNorm with
+    batch statistics because recon() leaves netMR in train mode (SURVEY C-2)."""
+    from pifuhd_amd import nets, synth
+    gold = np.load(os.path.join(golden_dir, 'filter_small.npz'))
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    assert netMR.training and not netG.training
+    netMR.filter_global(synth.synthetic_image(64, 3, seed=2))
+    assert _rel(netG.nmlF.cpu().numpy(), gold['tiny_nmlF']) < 1e-4
+    assert _rel(netG.nmlB.cpu().numpy(), gold['tiny_nmlB']) < 1e-4
+    fc = netG.im_feat_list[0].cpu().numpy()
+    assert fc.shape == gold['tiny_feat_coarse'].shape
+    assert _rel(fc, gold['tiny_feat_coarse']) < 2e-4
+    netMR.filter_local(synth.synthetic_image(128, 3, seed=3)[:, None])
+    ff = netMR.im_feat_list[0].cpu().numpy()
+    assert ff.shape == gold['tiny_feat_fine_trainmode'].shape
+    assert _rel(ff, gold['tiny_feat_fine_trainmode']) < 2e-4
+    # and the query path consumes the NHWC maps the encoder installed: compare with re-installing the NCHW export
+    calib = torch.eye(4)[None]; calib[0, 1, 1] = -1
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(1, 3, 2000, generator=g) * 2 - 1)
+    netMR.query(pts, calib)
+    a = netMR.get_preds().clone()
+    netG.set_features(netG.im_feat_list[0]); netMR.set_features(netMR.im_feat_list[0])
+    netMR.query(pts, calib)
+    assert torch.equal(a, netMR.get_preds())
+
+
+def test_filter_full_size_subsamples(golden_dir):
+    """512^2 filter_global and 1024^2 filter_local against strided sub-samples of the reference's outputs."""
+    from pifuhd_amd import config, nets, synth
+    gold = np.load(os.path.join(golden_dir, 'filter_full_sub.npz'))
+    oc = config.coarse_opt(); of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = synth.synthetic_inputs(1024, 3, seed=0)
+    netMR.filter_global(data['img_512'])
+    assert _rel(netG.nmlF[0, :, ::16, ::16].cpu().numpy(), gold['nmlF_sub']) < 2e-4
+    assert _rel(netG.nmlB[0, :, ::16, ::16].cpu().numpy(), gold['nmlB_sub']) < 2e-4
+    assert _rel(netG.im_feat_list[0][0, ::8, ::8, ::8].cpu().numpy(), gold['feat_coarse_sub']) < 5e-4
+    netMR.filter_local(data['img'][:, None])
+    assert _rel(netMR.im_feat_list[0][0, :, ::16, ::16].cpu().numpy(), gold['feat_fine_sub']) < 5e-4
+
+
+def test_group_norm_filter_variant(golden_dir):
+    """HGFilter with norm='group' (what the original PIFuHD checkpoints use), 'no_down', 9 -> 16 channels."""
+    import ctypes as C
+    from pifuhd_amd import _lib, synth
+    from pifuhd_amd.nets import _Ctx, _ptr, _stream_ptr
+    gold = np.load(os.path.join(golden_dir, 'filter_small.npz'))
+    spec = {}
+    synth.filter_keys('image_filter', 1, 2, 9, 16, 'group', 'no_down', spec)
+    sd = synth.name_seeded_state_dict(spec, seed=5, perturb=True)
+    ctx = _Ctx('cuda')
+    for k, t in sd.items():
+        a = np.ascontiguousarray(t.numpy().astype(np.float32))
+        shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+        _lib.call('pifu_enc_set_param', ctx.h, ('fine.' + k).encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 9, 64, 64, generator=g).cuda()
+    out = torch.empty(1, 16, 32, 32, device='cuda')
+    _lib.call('pifu_filter_fine', ctx.h, _ptr(x), 9, 64, 64, None, None, 64, 64, 1, 2, 16, 2, _ptr(out), _stream_ptr(ctx.device))
+    assert _rel(out.cpu().numpy(), gold['group_filter_out']) < 2e-4
