@@ -32,15 +32,20 @@ def _save_debug_png(path, image_tensor_global):
 
 def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None):
     """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`."""
-    t0 = time.perf_counter()
     dev = net.device
+
+    def mark():
+        if timings is not None:
+            torch.cuda.synchronize(dev)      # phase times are only meaningful once the queued kernels have finished
+        return time.perf_counter()
+    t0 = mark()
     image_tensor_global = data['img_512'].to(device=dev)
     image_tensor = data['img'].to(device=dev)
     calib_tensor = data['calib'].to(device=dev)
 
     net.filter_global(image_tensor_global)
     net.filter_local(image_tensor[:, None])
-    t1 = time.perf_counter()
+    t1 = mark()
 
     try:
         if net.netG.netF is not None:
@@ -52,13 +57,13 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     b_min = data['b_min']
     b_max = data['b_max']
     _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
-    t2 = time.perf_counter()
+    t2 = mark()
 
     # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
     # like the reference (reconstruction.py:56)
     verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, b_min, b_max, thresh, use_octree=use_octree,
                                         num_samples=5000)
-    t3 = time.perf_counter()
+    t3 = mark()
     verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
 
     color = np.zeros(verts.shape)
@@ -72,7 +77,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         net.calc_normal(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor)
         nml = net.nmls.detach().cpu().numpy()[0] * 0.5 + 0.5
         color[left:right] = nml.T
-    t4 = time.perf_counter()
+    t4 = mark()
 
     save_obj_mesh_with_color(save_path, verts, faces, color)
     t5 = time.perf_counter()
