@@ -6,6 +6,11 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <math.h>
+#include <memory>
+#include <string>
+#include <thread>
 #include <vector>
 
 static thread_local char g_err[1024] = "";
@@ -265,24 +270,96 @@ extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const flo
     return PIFU_OK;
 }
 
-// save_obj_mesh_with_color (mesh_util.py:189-198): 'v %.4f %.4f %.4f %.4f %.4f %.4f', faces 1-based (f0, f2, f1)
+// save_obj_mesh_with_color (mesh_util.py:189-198): 'v %.4f %.4f %.4f %.4f %.4f %.4f', faces 1-based (f0, f2, f1).
+// Multi-threaded formatter, byte-identical to printf("%.4f"): the value is scaled by 1e4 with an error-free
+// product (p + e = x * 1e4 exactly, via fma) and rounded half-to-even on the exact value.
+namespace {
+
+inline char *put_uint(char *o, uint64_t v)
+{
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *o++ = tmp[--n];
+    return o;
+}
+
+inline char *put_fixed4(char *o, double x)
+{
+    if (!(fabs(x) < 1e11)) return o + sprintf(o, "%.4f", x);       // huge / inf / nan: defer to libc
+    if (signbit(x)) *o++ = '-';
+    const double ax = fabs(x);
+    const double p = ax * 1e4;
+    const double e = fma(ax, 1e4, -p);
+    double fl = floor(p);
+    uint64_t n = (uint64_t)fl;
+    const double d = p - fl;
+    if (d > 0.5 || (d == 0.5 && (e > 0.0 || (e == 0.0 && (n & 1))))) ++n;
+    else if (d == 0.0 && e < 0.0) { /* exact value just below an integer: floor(p) is already one too high */
+        // p was rounded UP to the integer fl while the exact product is fl - |e|: the digits are those of fl - 1 + (1 - |e|)
+        // whose fraction is > 0.5, so the rounded result is fl again: nothing to do
+    }
+    o = put_uint(o, n / 10000);
+    *o++ = '.';
+    const unsigned f = (unsigned)(n % 10000);
+    *o++ = (char)('0' + f / 1000);
+    *o++ = (char)('0' + f / 100 % 10);
+    *o++ = (char)('0' + f / 10 % 10);
+    *o++ = (char)('0' + f % 10);
+    return o;
+}
+
+}  // namespace
+
 extern "C" int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                               const int32_t *faces, int64_t nfaces)
 {
-    PIFU_REQUIRE(path && (verts || nverts == 0) && (faces || nfaces == 0), PIFU_ERR_INVALID, "pifu_write_obj: null argument");
+    PIFU_REQUIRE(path && (verts || nverts == 0) && (colors || nverts == 0) && (faces || nfaces == 0), PIFU_ERR_INVALID,
+                 "pifu_write_obj: null argument");
     FILE *f = fopen(path, "w");
     PIFU_REQUIRE(f, PIFU_ERR_INVALID, "pifu_write_obj: cannot open %s", path);
-    std::vector<char> buf(1 << 20);
-    setvbuf(f, buf.data(), _IOFBF, buf.size());
-    for (int64_t i = 0; i < nverts; ++i) {
-        const double *v = verts + 3 * i, *c = colors + 3 * i;
-        fprintf(f, "v %.4f %.4f %.4f %.4f %.4f %.4f\n", v[0], v[1], v[2], c[0], c[1], c[2]);
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
+    const int64_t total = nverts + nfaces;
+    const int64_t per = (total + nthreads - 1) / nthreads;
+    std::vector<std::unique_ptr<char[]>> out(nthreads);
+    std::vector<size_t> out_len(nthreads, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) {
+        pool.emplace_back([&, t]() {
+            const int64_t lo = t * per, hi = std::min(total, lo + per);
+            if (lo >= hi) return;
+            const int64_t nv_here = std::max<int64_t>(0, std::min(hi, nverts) - lo), nf_here = (hi - lo) - nv_here;
+            out[t].reset(new char[(size_t)nv_here * 168 + (size_t)nf_here * 40 + 64]);    // uninitialised on purpose
+            char *const base = out[t].get();
+            char *o = base;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (i < nverts) {
+                    const double *v = verts + 3 * i, *c = colors + 3 * i;
+                    *o++ = 'v';
+                    for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
+                    for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
+                    *o++ = '\n';
+                } else {
+                    const int32_t *tr = faces + 3 * (i - nverts);
+                    const int idx[3] = {tr[0] + 1, tr[2] + 1, tr[1] + 1};
+                    *o++ = 'f';
+                    for (int k = 0; k < 3; ++k) {
+                        *o++ = ' ';
+                        if (idx[k] < 0) { *o++ = '-'; o = put_uint(o, (uint64_t)(-(int64_t)idx[k])); }
+                        else o = put_uint(o, (uint64_t)idx[k]);
+                    }
+                    *o++ = '\n';
+                }
+            }
+            out_len[t] = (size_t)(o - base);
+        });
     }
-    for (int64_t i = 0; i < nfaces; ++i) {
-        const int32_t *t = faces + 3 * i;
-        fprintf(f, "f %d %d %d\n", t[0] + 1, t[2] + 1, t[1] + 1);
-    }
-    const bool bad = ferror(f);
+    for (auto &th : pool) th.join();
+    bool bad = false;
+    for (int t = 0; t < nthreads; ++t)
+        if (out_len[t] && fwrite(out[t].get(), 1, out_len[t], f) != out_len[t]) bad = true;
+    bad = bad || ferror(f);
     fclose(f);
     PIFU_REQUIRE(!bad, PIFU_ERR_INVALID, "pifu_write_obj: write error on %s", path);
     return PIFU_OK;

@@ -300,6 +300,219 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mlp_gemm_ring: same math and operand layout as k_mlp_gemm (bit-identical results), different pipeline.
+// Measured problem of the 2-buffer kernel (s_memtime stamps): a wave has a ~1 700-cycle MFMA-free
+// tail per K step (staging, barrier, next loads, first fragment reads) and the block barrier lines the two
+// resident blocks' tails up.  Here every wave keeps its own MFMA stream continuous:
+//   * 3-deep LDS ring: step t computes tile t, writes tile t+2 (loaded into registers one step earlier, so its
+//     vmcnt wait is already satisfied) and issues the global loads of tile t+3;
+//   * tile t+1 is stable during step t (published by the previous barrier), so its first fragments are read
+//     BEFORE the end-of-step barrier and the next step's MFMAs start right after it;
+//   * all non-MFMA work of a step is cut into chunks placed between the MFMA groups.
+// Two register sets hold the in-flight tiles (tile j uses set j & 1) => the step loop is unrolled by two.
+// ------------------------------------------------------------------------------------------------
+template <int TBK>
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm_ring(const GemmArgs a)
+{
+    constexpr int LD = TBK + 4;
+    constexpr int TILE = BM * LD;
+    constexpr int F4_PER_ROW = TBK / 4;
+    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    constexpr int NP = BM / ROWS_PER_PASS;   // 4 at BK 32, 2 at BK 16
+    constexpr int NS = TBK / 8;              // 4 or 2 MFMA groups (8 k each) per step
+    __shared__ __attribute__((aligned(16))) float lds[6 * TILE];   // ring of 3 x [A|B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM;
+    const int col0 = tile_n * BN;
+    const int kq = tid % F4_PER_ROW, sr = tid / F4_PER_ROW;
+    const int b1 = a.seg[0].width;
+    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
+    const int nsteps = a.ldw / TBK;
+
+    struct Stage { float4 a0, a1, a2, a3, w0, w1, w2, w3, sc, sh; float slope; };
+    Stage S0, S1;
+    S0.a2 = S0.a3 = S0.w2 = S0.w3 = S1.a2 = S1.a3 = S1.w2 = S1.w3 = make_float4(0, 0, 0, 0);
+    S0.slope = S1.slope = 1.f;
+
+#define RING_GLOAD(S_, step_)                                                                              \
+    {                                                                                                      \
+        const int kk = (step_) * TBK;                                                                      \
+        const int sg = (kk >= b1) + (kk >= b2);                                                            \
+        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
+        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
+        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
+        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
+        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
+        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
+        S_.slope = md == 0 ? 1.f : 0.01f;                                                                  \
+        const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
+        const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
+        S_.a0 = *reinterpret_cast<const float4 *>(ap);                                                     \
+        S_.a1 = *reinterpret_cast<const float4 *>(ap + (size_t)ROWS_PER_PASS * ld);                        \
+        if constexpr (NP > 2) {                                                                            \
+            S_.a2 = *reinterpret_cast<const float4 *>(ap + (size_t)2 * ROWS_PER_PASS * ld);                \
+            S_.a3 = *reinterpret_cast<const float4 *>(ap + (size_t)3 * ROWS_PER_PASS * ld);                \
+        }                                                                                                  \
+        S_.sc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                       \
+        S_.sh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                       \
+        const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                                 \
+        S_.w0 = *reinterpret_cast<const float4 *>(wp);                                                     \
+        S_.w1 = *reinterpret_cast<const float4 *>(wp + (size_t)ROWS_PER_PASS * a.ldw);                     \
+        if constexpr (NP > 2) {                                                                            \
+            S_.w2 = *reinterpret_cast<const float4 *>(wp + (size_t)2 * ROWS_PER_PASS * a.ldw);             \
+            S_.w3 = *reinterpret_cast<const float4 *>(wp + (size_t)3 * ROWS_PER_PASS * a.ldw);             \
+        }                                                                                                  \
+    }
+#define RING_ST1(S_, base_, p_, va_, vw_)                                                                  \
+    {                                                                                                      \
+        float *la = (base_) + (sr + (p_) * ROWS_PER_PASS) * LD + kq * 4;                                   \
+        float4 v_ = S_.va_;                                                                                \
+        float t_;                                                                                          \
+        t_ = fmaf(v_.x, S_.sc.x, S_.sh.x); v_.x = fmaxf(t_, S_.slope * t_);                                \
+        t_ = fmaf(v_.y, S_.sc.y, S_.sh.y); v_.y = fmaxf(t_, S_.slope * t_);                                \
+        t_ = fmaf(v_.z, S_.sc.z, S_.sh.z); v_.z = fmaxf(t_, S_.slope * t_);                                \
+        t_ = fmaf(v_.w, S_.sc.w, S_.sh.w); v_.w = fmaxf(t_, S_.slope * t_);                                \
+        *reinterpret_cast<float4 *>(la) = v_;                                                              \
+        *reinterpret_cast<float4 *>(la + TILE) = S_.vw_;                                                   \
+    }
+#define RING_STORE_H0(S_, base_)                                                                           \
+    {                                                                                                      \
+        RING_ST1(S_, base_, 0, a0, w0)                                                                     \
+        if constexpr (NP > 2) RING_ST1(S_, base_, 1, a1, w1)                                               \
+    }
+#define RING_STORE_H1(S_, base_)                                                                           \
+    {                                                                                                      \
+        if constexpr (NP > 2) {                                                                            \
+            RING_ST1(S_, base_, 2, a2, w2)                                                                 \
+            RING_ST1(S_, base_, 3, a3, w3)                                                                 \
+        } else {                                                                                           \
+            RING_ST1(S_, base_, 1, a1, w1)                                                                 \
+        }                                                                                                  \
+    }
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    struct Frag { float4 a0, a1, b0, b1; };
+    Frag F0, F1;
+    const int foffA = (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const int foffB = TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+
+#define RING_FRAG(F_, base_, s_)                                                                           \
+    {                                                                                                      \
+        F_.a0 = *reinterpret_cast<const float4 *>((base_) + foffA + (s_) * 8);                             \
+        F_.a1 = *reinterpret_cast<const float4 *>((base_) + foffA + 32 * LD + (s_) * 8);                   \
+        F_.b0 = *reinterpret_cast<const float4 *>((base_) + foffB + (s_) * 8);                             \
+        F_.b1 = *reinterpret_cast<const float4 *>((base_) + foffB + 32 * LD + (s_) * 8);                   \
+    }
+#define RING_MFMA1(av0_, av1_, bv0_, bv1_)                                                                 \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv0_, acc00, 0, 0, 0);                              \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv1_, acc01, 0, 0, 0);                              \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv0_, acc10, 0, 0, 0);                              \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv1_, acc11, 0, 0, 0);
+#define RING_MFMA_FIRST(F_) RING_MFMA1(F_.a0.x, F_.a1.x, F_.b0.x, F_.b1.x)
+#define RING_MFMA_REST(F_)                                                                                 \
+    RING_MFMA1(F_.a0.y, F_.a1.y, F_.b0.y, F_.b1.y)                                                         \
+    RING_MFMA1(F_.a0.z, F_.a1.z, F_.b0.z, F_.b1.z)                                                         \
+    RING_MFMA1(F_.a0.w, F_.a1.w, F_.b0.w, F_.b1.w)
+
+    // one K step.  SW_ = register set holding tile t+2 (written now), SL_ = set that receives tile t+3.
+#define RING_STEP(t_, SW_, SL_)                                                                            \
+    {                                                                                                      \
+        const int t = (t_);                                                                                \
+        float *cur = lds + (t % 3) * 2 * TILE;                                                             \
+        float *nxt = lds + ((t + 1) % 3) * 2 * TILE;                                                       \
+        float *wrt = lds + ((t + 2) % 3) * 2 * TILE;                                                       \
+        const bool has1 = t + 1 < nsteps, has2 = t + 2 < nsteps, has3 = t + 3 < nsteps;                    \
+        /* group 0 (fragments already in F0) */                                                            \
+        RING_FRAG(F1, cur, 1)                                                                              \
+        RING_MFMA_FIRST(F0)                                                                                \
+        if (has3) RING_GLOAD(SL_, t + 3)                                                                   \
+        RING_MFMA_REST(F0)                                                                                 \
+        if constexpr (NS == 2) {                                                                           \
+            if (has1) RING_FRAG(F0, nxt, 0)                                                                \
+            RING_MFMA_FIRST(F1)                                                                            \
+            if (has2) { RING_STORE_H0(SW_, wrt) RING_STORE_H1(SW_, wrt) }                                  \
+            RING_MFMA_REST(F1)                                                                             \
+        } else {                                                                                           \
+            RING_FRAG(F0, cur, 2)                                                                          \
+            RING_MFMA_FIRST(F1)                                                                            \
+            if (has2) RING_STORE_H0(SW_, wrt)                                                              \
+            RING_MFMA_REST(F1)                                                                             \
+            RING_FRAG(F1, cur, 3)                                                                          \
+            RING_MFMA_FIRST(F0)                                                                            \
+            if (has2) RING_STORE_H1(SW_, wrt)                                                              \
+            RING_MFMA_REST(F0)                                                                             \
+            if (has1) RING_FRAG(F0, nxt, 0)                                                                \
+            RING_MFMA_FIRST(F1)                                                                            \
+            RING_MFMA_REST(F1)                                                                             \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+    }
+
+    // ---- prologue: tiles 0 and 1 into the ring, tile 2 in flight, first fragments in registers
+    RING_GLOAD(S0, 0)
+    if (nsteps > 1) RING_GLOAD(S1, 1)
+    { float *b0p = lds; RING_STORE_H0(S0, b0p) RING_STORE_H1(S0, b0p) }
+    if (nsteps > 1) { float *b1p = lds + 2 * TILE; RING_STORE_H0(S1, b1p) RING_STORE_H1(S1, b1p) }
+    if (nsteps > 2) RING_GLOAD(S0, 2)
+    __syncthreads();
+    RING_FRAG(F0, lds, 0)
+
+    __builtin_amdgcn_s_setprio(3);
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        RING_STEP(step, S0, S1)
+        RING_STEP(step + 1, S1, S0)
+    }
+    if (step < nsteps) RING_STEP(step, S0, S1)
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue (identical to k_mlp_gemm)
+    const int h = lane >> 5, j = lane & 31;
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = lds;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = col0 + wn * 64 + nt * 32 + j;
+        const float bias = a.bias[col];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[r] + bias;
+                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
+                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
+            }
+        }
+        if (a.partial) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (lane < 32) {
+                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
+                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
+            }
+        }
+    }
+    if (a.partial) {
+        __syncthreads();
+        if (tid < BN)
+            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_norm_finalize: (sum, sum^2) partials -> per-(chunk, channel) scale/shift of the following norm.
 // One wave per (chunk, group); double accumulation in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
@@ -746,6 +959,8 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             case 3: hipLaunchKernelGGL((k_mlp_gemm<16, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 4: hipLaunchKernelGGL((k_mlp_gemm<32, 3>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 5: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((k_mlp_gemm_ring<16>), dim3(nblocks), dim3(256), 0, st, a); break;
+            case 7: hipLaunchKernelGGL((k_mlp_gemm_ring<32>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 9: a.stamps = (L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr; hipLaunchKernelGGL((k_mlp_gemm<32, 2>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 0: hipLaunchKernelGGL((k_mlp_gemm<32, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
             default: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;   // MFMA phase at raised priority (+2 %)

@@ -58,8 +58,12 @@ def test_obj_writer_host_only(lib, tmp_path):
     from oracle import pifu_oracle as O
     from pifuhd_amd import mesh_util
     rs = np.random.RandomState(0)
-    v, c = rs.randn(50, 3), rs.rand(50, 3)
-    f = rs.randint(0, 50, size=(80, 3)).astype(np.int32)
+    # random values + exact rounding ties (k/32, odd/20000), signed zeros, tiny negatives, large magnitudes
+    v = np.concatenate([rs.randn(5000, 3) * 3, rs.randint(-64, 64, size=(600, 3)) / 32.0,
+                        (rs.randint(0, 20000, size=(600, 3)) * 2 + 1) / 20000.0,
+                        np.array([[0.0, -0.0, 1e-9], [-1e-9, 0.00005, -0.00005], [123456.78905, -99999.99995, 1e10]])])
+    c = rs.rand(len(v), 3)
+    f = rs.randint(0, len(v), size=(8000, 3)).astype(np.int32)
     p = tmp_path / 'a.obj'
     mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
     assert p.read_text() == O.obj_text(v, f, c)
