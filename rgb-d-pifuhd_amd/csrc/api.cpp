@@ -61,6 +61,10 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
     PIFU_HIP(hipSetDevice(device));
     pifu_ctx *c = new pifu_ctx();
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
@@ -78,7 +82,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
             return PIFU_ERR_HIP;
         }
     }
-    if (c->gemm_variant == 9) { (void)hipMalloc(&c->debug_buf, (64 * 40 * 4 + 16384 * 16) * 8); (void)hipMemset(c->debug_buf, 0, (64 * 40 * 4 + 16384 * 16) * 8); }
+    if (c->gemm_variant == 9 || getenv("PIFU_DEBUG_STAMPS")) { (void)hipMalloc(&c->debug_buf, (64 * 40 * 4 + 16384 * 16) * 8); (void)hipMemset(c->debug_buf, 0, (64 * 40 * 4 + 16384 * 16) * 8); }
     *out = c;
     return PIFU_OK;
 }

@@ -99,6 +99,7 @@ struct pifu_ctx {
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
     float *ident_scale = nullptr, *ident_shift = nullptr;   // device ones / zeros [PIFU_MAX_WIDTH]
     // optional per-launch timing of the dominant kernel (k_mlp_gemm) with HIP events on the launch stream
+    int num_cus = 256;
     void *debug_buf = nullptr;            // diagnostics only
     int gemm_variant = 5;                 // schedule variant of k_mlp_gemm (env PIFU_GEMM_VARIANT; tuning aid)
     bool prof_on = false;
