@@ -66,6 +66,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
+    if (const char *v = getenv("PIFU_COLUMN_MODE")) c->col_enable = atoi(v);
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         pifu_set_error("pinned host allocation failed");
@@ -98,7 +99,7 @@ extern "C" int pifu_debug_read(pifu_ctx *ctx, void *host, size_t bytes)
 
 static void free_layer(MlpLayer &l)
 {
-    float **ptrs[] = {&l.w, &l.bias, &l.gamma, &l.beta, &l.fixed_scale, &l.fixed_shift};
+    float **ptrs[] = {&l.w, &l.bias, &l.gamma, &l.beta, &l.fixed_scale, &l.fixed_shift, &l.w_col, &l.wz};
     for (float **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -118,9 +119,11 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
         for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(ctx->mlp[L].layer[i]);
         if (ctx->feat[L].nhwc) (void)hipFree(ctx->feat[L].nhwc);
     }
-    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc};
+    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc, &ctx->col_arena};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (int L = 0; L < 2; ++L)
+        if (ctx->mlp[L].colW) (void)hipFree(ctx->mlp[L].colW);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
@@ -161,6 +164,7 @@ extern "C" int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, in
     PIFU_HIP(hipSetDevice(ctx->device));
     Mlp &m = ctx->mlp[level];
     for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(m.layer[i]);
+    if (m.colW) { (void)hipFree(m.colW); m.colW = nullptr; }
     m = Mlp();
     m.ndims = ndims;
     m.nlayers = ndims - 1;
@@ -251,6 +255,9 @@ extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const flo
     for (int o = 0; o < l.cout; ++o) b[o] = bias[o];
     if ((rc = upload(&l.bias, b))) return rc;
     l.host_bias0 = bias[0];
+    l.host_w.assign(weight, weight + (size_t)l.cout * cin);
+    m.col_built = false;
+    if (level == 0) ctx->mlp[1].col_built = false;
     if (l.has_norm) {
         std::vector<float> g(l.cout_pad, 0.f), be(l.cout_pad, 0.f), fs(l.cout_pad, 0.f), fb(l.cout_pad, 0.f);
         if (m.norm != PIFU_NORM_NONE) {

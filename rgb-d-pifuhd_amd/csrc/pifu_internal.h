@@ -52,6 +52,13 @@ struct MlpLayer {
     float *gamma = nullptr, *beta = nullptr;       // device [cout_pad] (affine of the norm)
     float *fixed_scale = nullptr, *fixed_shift = nullptr;  // device [cout_pad] for NONE / BATCH_EVAL
     float host_bias0 = 0.f; // bias of a 1-channel (last) layer, kept on the host
+    // column sharing (lattice sources): weights without the skip input's per-column part
+    std::vector<float> host_w;   // [cout][cin] as given
+    float *w_col = nullptr;      // device [cout_pad | 1][kpad_col]
+    int kpad_col = 0, cin_col = 0;
+    float *wz = nullptr;         // device [cout_pad]: weight of the depth feature (coarse level)
+    float host_wz0 = 0.f;
+    int col_off = -1;            // first column of this layer's block in the column table (-1: none)
     bool set = false;
 };
 
@@ -64,6 +71,10 @@ struct Mlp {
     int norm = PIFU_NORM_GROUP;
     int nlayers = 0;
     MlpLayer layer[PIFU_MAX_LAYERS];
+    // column sharing: stacked per-column weights [col_rows][col_k] (image-feature columns of layer 0 / res layers)
+    float *colW = nullptr;
+    int col_rows = 0, col_k = 0;
+    bool col_built = false;
 };
 
 struct FeatMap {
@@ -94,6 +105,9 @@ struct pifu_ctx {
     McState mc;
     // octree scratch
     DevBuf oct_arena;
+    // column tables of the lattice evaluation (column sharing)
+    DevBuf col_arena;
+    int col_enable = 1;
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs

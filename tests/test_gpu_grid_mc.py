@@ -153,3 +153,37 @@ def test_obj_writer(tmp_path):
     p = tmp_path / 'm.obj'
     mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
     assert p.read_text() == O.obj_text(v, f, c)
+
+
+def test_column_sharing_equals_per_point_evaluation():
+    """Lattice evaluation shares the image-feature products of an (i, j) column; the result must agree with the
+    independent per-point evaluation up to fp32 summation order, for dense ranges (incl. one that starts in the
+    middle of a column) and for an octree-style index list."""
+    import ctypes as C
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(9)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = np.ascontiguousarray(calib_tensor()[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    res = (C.c_int32 * 3)(24, 40, 48)
+
+    def run(flags, index, first, count):
+        out = torch.empty(count, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  _ptr(index), first, count, 5000, flags, _ptr(out), _stream_ptr(netMR.device))
+        return out.cpu().numpy()
+    total = 24 * 40 * 48
+    for first, count in ((0, total), (5000 * 3, 5000 * 2 + 777)):
+        a = run(_lib.Q_FULL_COARSE, None, first, count)
+        b = run(_lib.Q_FULL_COARSE | _lib.Q_NO_COLUMN_SHARING, None, first, count)
+        assert np.abs(a - b).max() < 2e-5
+        assert np.abs(a - b).max() > 0          # the two paths really are different computations
+    g = torch.Generator().manual_seed(3)
+    idx = torch.sort(torch.randperm(total, generator=g)[:12345])[0].cuda()
+    a = run(0, idx, 0, 12345)
+    b = run(_lib.Q_NO_COLUMN_SHARING, idx, 0, 12345)
+    assert np.abs(a - b).max() < 2e-5
