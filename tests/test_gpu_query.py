@@ -115,3 +115,48 @@ def test_errors_are_loud():
         netG.query(seeded_points(1, 10), calib_tensor())        # filter must precede query
     with pytest.raises(NotImplementedError):
         nets.PIFuNetwNML(oc, 'perspective', 'cuda')
+
+
+@pytest.mark.parametrize('n', [1, 127, 128, 129, 5001])
+def test_ragged_sizes_vs_oracle(n):
+    """Tile-boundary sizes: one chunk of n points (padding rows must not leak into the statistics)."""
+    from oracle import pifu_oracle as O
+    from helpers import mlp_only_nets
+    from pifuhd_amd import nets
+    sd, oc, of = mlp_only_nets()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda'); netMR = nets.PIFuMRNet(of, netG); netG.eval()
+    netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}; netG._push_weights()
+    netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}; netMR._push_weights()
+    fc, ff = seeded_features(7)
+    netG.set_features(fc); netMR.set_features(ff)
+    pts = seeded_points(30 + n, n, lim=1.05)
+    calib = calib_tensor()
+    netMR.query(pts, calib)
+    got = netMR.get_preds()[0, 0].cpu().numpy()
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    with torch.no_grad():
+        want = ref.query(pts, calib)[0, 0].numpy()
+    if n == 1:
+        # GroupNorm over a single point: variance of a handful of channels; both sides are ill-conditioned the same way
+        assert np.abs(got - want).max() < 5e-3
+    else:
+        assert np.abs(got - want).max() < TOL
+
+
+def test_empty_and_bad_arguments():
+    import ctypes as C
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netG, netMR, *_ = _build()
+    cal = np.ascontiguousarray(calib_tensor()[0].numpy())
+    out = torch.empty(4, device='cuda')
+    pts = seeded_points(1, 4).cuda().contiguous()
+    # n = 0 is a no-op (the reference's batch_eval never calls eval_func for an empty level)
+    _lib.call('pifu_query', netMR._ctx.h, _ptr(pts), 0, cal.ctypes.data_as(C.c_void_p), 5000, 0, _ptr(out), None, None,
+              _stream_ptr(netMR.device))
+    with pytest.raises(_lib.PifuError):
+        _lib.call('pifu_query', netMR._ctx.h, _ptr(pts), 4, cal.ctypes.data_as(C.c_void_p), 0, 0, _ptr(out), None, None,
+                  _stream_ptr(netMR.device))
+    with pytest.raises(RuntimeError):
+        netMR.calc_normal(pts[:, None, :, :0], calib_tensor()[:, None], calib_tensor())      # SURVEY C-6

@@ -15,15 +15,16 @@ os.makedirs('profiles', exist_ok=True)
 
 
 def short(name):
-    name = name.replace('(anonymous namespace)::', '')
-    return name.split('(')[0][:60]
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    name = name.split('(')[0]
+    return name.split('<')[0][:60] if name.startswith('k_') else name[:60]
 
 
 # (1) kernel stats
 stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --features synthetic '
+    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 '
             '--no-cpu-baseline --no-genmesh   (MI355X, 1 GPU)\n')
     f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
     for r in rows[:12]:
@@ -52,7 +53,7 @@ g = sq.get('k_mlp_gemm', {})
 if g:
     summary['k_mlp_gemm_sq'] = {c: sum(v) / len(v) for c, v in g.items()}
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --res 128 '
-                     '--features synthetic (same per-launch geometry as the headline run: 51 chunks x 5120 rows)',
+                     '(same per-launch geometry as the headline run: 51 chunks x 5120 rows)',
            'k_mlp_gemm_hbm_bytes_per_launch': summary.get('k_mlp_gemm', {}).get('hbm_bytes_per_launch'),
            'detail': summary}, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(summary, indent=1))
