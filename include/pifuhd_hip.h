@@ -76,6 +76,9 @@ int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, int ndims,
 int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight, const float *bias,
                        const float *norm_weight, const float *norm_bias,
                        const float *running_mean, const float *running_var);
+/* Arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default, ~1e-6 from the reference); 1 = bf16 x 3 split precision
+ * on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation; ~1e-5 on the occupancy, inside the 1e-4 contract). */
+int pifu_set_precision(pifu_ctx *ctx, int mode);
 /* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
  * z_div = z_size of the COARSE net's options. */
 int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);

@@ -67,6 +67,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
     }
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
     if (const char *v = getenv("PIFU_COLUMN_MODE")) c->col_enable = atoi(v);
+    if (const char *v = getenv("PIFU_PRECISION")) c->precision = atoi(v);
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         pifu_set_error("pinned host allocation failed");
@@ -125,6 +126,7 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     for (int L = 0; L < 2; ++L)
         if (ctx->mlp[L].colW) (void)hipFree(ctx->mlp[L].colW);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
@@ -142,6 +144,14 @@ extern "C" int pifu_reserve(pifu_ctx *ctx, int64_t rows)
 extern "C" int64_t pifu_workspace_bytes(pifu_ctx *ctx)
 {
     return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes) : 0;
+}
+
+// 0 = exact fp32 MFMA (default); 1 = bf16 x 3 split precision (fp32 accumulate, ~1e-5 on the occupancy)
+extern "C" int pifu_set_precision(pifu_ctx *ctx, int mode)
+{
+    PIFU_REQUIRE(ctx && (mode == 0 || mode == 1), PIFU_ERR_INVALID, "pifu_set_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+    ctx->precision = mode;
+    return PIFU_OK;
 }
 
 extern "C" int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div)
@@ -256,6 +266,8 @@ extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const flo
     if ((rc = upload(&l.bias, b))) return rc;
     l.host_bias0 = bias[0];
     l.host_w.assign(weight, weight + (size_t)l.cout * cin);
+    for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);      // device addresses may be reused by new weights
+    ctx->bf16_planes.clear();
     m.col_built = false;
     if (level == 0) ctx->mlp[1].col_built = false;
     if (l.has_norm) {

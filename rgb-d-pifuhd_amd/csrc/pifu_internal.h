@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,10 @@ struct pifu_ctx {
     // optional per-launch timing of the dominant kernel (k_mlp_gemm) with HIP events on the launch stream
     int num_cus = 256;
     void *debug_buf = nullptr;            // diagnostics only
+    // arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default), 1 = bf16 x 3 split precision on the bf16 matrix cores
+    int precision = 0;
+    struct Planes { void *hi; void *lo; size_t n; };
+    std::map<const void *, Planes> bf16_planes;
     int gemm_variant = 5;                 // schedule variant of k_mlp_gemm (env PIFU_GEMM_VARIANT; tuning aid)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)

@@ -52,6 +52,7 @@ struct GemmArgs {
     Seg seg[3];
     int nseg;
     const float *W;   // [cout_pad][ldw]
+    const __bf16 *Whi, *Wlo;   // split-precision planes of W (k_mlp_gemm_bf3), same shape
     int ldw;          // = padded K
     const float *bias;
     float *Y;         // [rows][ldy]
@@ -937,6 +938,261 @@ __global__ __launch_bounds__(512, 2) void k_mlp_gemm_ws(const GemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mlp_gemm_bf3: opt-in split-precision version of the MLP GEMM on the bf16 matrix cores.
+// Every fp32 operand x is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32), and
+// the product is accumulated in fp32 as  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  (the lo*lo term, 2^-16 relative, is
+// dropped).  3 x v_mfma_f32_32x32x16_bf16 (32 cycles each) replace 8 x v_mfma_f32_32x32x2_f32 (64 cycles each) per
+// 32x32x16 block: 5.3x fewer matrix cycles.  Measured effect on the occupancy: ~1e-5 (SURVEY section 7 probe: 1.9e-6 ..
+// 1.2e-5), inside the 1e-4 contract; the exact-fp32 kernel stays the default.  Same tiles, same fused prologue and
+// epilogue, same K order per product.  W is split once per layer (k_split_bf16); A is split while it is staged.
+// LDS (per buffer): A_hi, A_lo, W_hi, W_lo as [128 rows][32 k] bf16 with an 80-byte row stride (conflict-free
+// ds_read_b128: lane (r, h) reads the 8 k values 8h..8h+7 of row r = one MFMA operand).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_split_bf16(const float *W, __bf16 *hi, __bf16 *lo, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = W[i];
+    const __bf16 h = (__bf16)x;
+    hi[i] = h;
+    lo[i] = (__bf16)(x - (float)h);
+}
+
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
+{
+    constexpr int TBK = 32;
+    constexpr int RS = 32;                       // row stride in bf16 elements (64 B); 16-byte chunks XOR-swizzled by (row >> 2) & 3
+    constexpr int PLANE = BM * RS;               // one [128][32] bf16 plane
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * PLANE];   // [buf][A_hi | A_lo | W_hi | W_lo] = 65,536 B
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM;
+    const int col0 = tile_n * BN;
+    const int kq = tid & 7, sr = tid >> 3;       // A staging: float4 column kq of rows sr + 32 p
+    const int wq = tid & 3, wr = tid >> 2;       // W staging: 8 bf16 (16 B) column wq of rows wr + 64 p
+    const int b1 = a.seg[0].width;
+    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
+    const int nsteps = a.ldw / TBK;
+
+    // Operands are prefetched TWO K steps ahead into two register sets (step j lives in set j & 1): with the short
+    // bf16 MFMA phase a one-step-ahead prefetch would stall on the global-load latency at every staging pass.
+    struct Stage { float4 a0, a1, a2, a3, sc, sh; bf16x8 wh0, wh1, wl0, wl1; float slope; };
+    Stage S0, S1;
+    S0.slope = S1.slope = 1.f;
+
+    // lean operand fetch: per-step descriptors come from the kernarg table (scalar loads, prefetched one call ahead),
+    // addresses are uniform base + 32-bit lane offset
+    const unsigned r0 = tile_m * BM + sr, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
+    const unsigned kb4 = kq * 16;
+    const unsigned ldw2 = a.ldw * 2;                                       // bytes per row of a bf16 plane
+    const unsigned wo0 = (col0 + wr) * ldw2 + wq * 16, wo1 = wo0 + 64 * ldw2;
+    const bool use_table = a.nsteps > 0;
+    const float *d_ptr = a.steps[0].ptr, *d_scale = a.steps[0].scale, *d_shift = a.steps[0].shift;
+    unsigned d_ld4 = a.steps[0].ld4;
+    int d_sld = a.steps[0].sld, d_mode = a.steps[0].mode, d_next = 1;
+#define BF3_GLOAD(S_, step_)                                                                               \
+    if (use_table) {                                                                                       \
+        const char *ab = reinterpret_cast<const char *>(d_ptr);                                            \
+        S_.slope = d_mode == 0 ? 1.f : 0.01f;                                                              \
+        S_.a0 = *reinterpret_cast<const float4 *>(ab + (__umul24(r0, d_ld4) + kb4));                       \
+        S_.a1 = *reinterpret_cast<const float4 *>(ab + (__umul24(r1, d_ld4) + kb4));                       \
+        S_.a2 = *reinterpret_cast<const float4 *>(ab + (__umul24(r2, d_ld4) + kb4));                       \
+        S_.a3 = *reinterpret_cast<const float4 *>(ab + (__umul24(r3, d_ld4) + kb4));                       \
+        const char *sb = reinterpret_cast<const char *>(d_scale + (size_t)chunk_id * d_sld);               \
+        const char *hb = reinterpret_cast<const char *>(d_shift + (size_t)chunk_id * d_sld);               \
+        S_.sc = *reinterpret_cast<const float4 *>(sb + kb4);                                               \
+        S_.sh = *reinterpret_cast<const float4 *>(hb + kb4);                                               \
+        const char *whb = reinterpret_cast<const char *>(a.Whi + (step_) * TBK);                           \
+        const char *wlb = reinterpret_cast<const char *>(a.Wlo + (step_) * TBK);                           \
+        S_.wh0 = *reinterpret_cast<const bf16x8 *>(whb + wo0);                                             \
+        S_.wh1 = *reinterpret_cast<const bf16x8 *>(whb + wo1);                                             \
+        S_.wl0 = *reinterpret_cast<const bf16x8 *>(wlb + wo0);                                             \
+        S_.wl1 = *reinterpret_cast<const bf16x8 *>(wlb + wo1);                                             \
+        const int nx_ = d_next < nsteps ? d_next : nsteps - 1;                                             \
+        const GemmArgs::StepDesc &dn = a.steps[nx_];                                                       \
+        d_ptr = dn.ptr; d_scale = dn.scale; d_shift = dn.shift; d_ld4 = dn.ld4; d_sld = dn.sld; d_mode = dn.mode; \
+        ++d_next;                                                                                          \
+    } else {                                                                                               \
+        const int kk = (step_) * TBK;                                                                      \
+        const int sg = (kk >= b1) + (kk >= b2);                                                            \
+        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
+        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
+        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
+        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
+        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
+        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
+        S_.slope = md == 0 ? 1.f : 0.01f;                                                                  \
+        const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
+        const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
+        S_.a0 = *reinterpret_cast<const float4 *>(ap);                                                     \
+        S_.a1 = *reinterpret_cast<const float4 *>(ap + (size_t)32 * ld);                                   \
+        S_.a2 = *reinterpret_cast<const float4 *>(ap + (size_t)64 * ld);                                   \
+        S_.a3 = *reinterpret_cast<const float4 *>(ap + (size_t)96 * ld);                                   \
+        S_.sc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                       \
+        S_.sh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                       \
+        const size_t wo = (size_t)(col0 + wr) * a.ldw + kk + wq * 8;                                       \
+        S_.wh0 = *reinterpret_cast<const bf16x8 *>(a.Whi + wo);                                            \
+        S_.wh1 = *reinterpret_cast<const bf16x8 *>(a.Whi + wo + (size_t)64 * a.ldw);                       \
+        S_.wl0 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo);                                            \
+        S_.wl1 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo + (size_t)64 * a.ldw);                       \
+    }
+    // transform, split into hi / lo and write one float4 (4 k) of A
+#define BF3_STA(S_, base_, p_, va_)                                                                        \
+    {                                                                                                      \
+        const float4 v_ = S_.va_;                                                                          \
+        float t0_ = fmaf(v_.x, S_.sc.x, S_.sh.x), t1_ = fmaf(v_.y, S_.sc.y, S_.sh.y);                      \
+        float t2_ = fmaf(v_.z, S_.sc.z, S_.sh.z), t3_ = fmaf(v_.w, S_.sc.w, S_.sh.w);                      \
+        t0_ = fmaxf(t0_, S_.slope * t0_); t1_ = fmaxf(t1_, S_.slope * t1_);                                \
+        t2_ = fmaxf(t2_, S_.slope * t2_); t3_ = fmaxf(t3_, S_.slope * t3_);                                \
+        bf16x4 h_, l_;                                                                                     \
+        h_[0] = (__bf16)t0_; h_[1] = (__bf16)t1_; h_[2] = (__bf16)t2_; h_[3] = (__bf16)t3_;                \
+        l_[0] = (__bf16)(t0_ - (float)h_[0]); l_[1] = (__bf16)(t1_ - (float)h_[1]);                        \
+        l_[2] = (__bf16)(t2_ - (float)h_[2]); l_[3] = (__bf16)(t3_ - (float)h_[3]);                        \
+        const int row_ = sr + 32 * (p_);                                                                   \
+        __bf16 *d_ = (base_) + row_ * RS + (((kq >> 1) ^ ((row_ >> 2) & 3)) << 3) + (kq & 1) * 4;           \
+        *reinterpret_cast<bf16x4 *>(d_) = h_;                                                              \
+        *reinterpret_cast<bf16x4 *>(d_ + PLANE) = l_;                                                      \
+    }
+#define BF3_LSTORE(S_, buf_)                                                                               \
+    {                                                                                                      \
+        __bf16 *base = lds + (buf_) * 4 * PLANE;                                                           \
+        BF3_STA(S_, base, 0, a0) BF3_STA(S_, base, 1, a1) BF3_STA(S_, base, 2, a2) BF3_STA(S_, base, 3, a3) \
+        /* rows wr and wr + 64 have the same (row >> 2) & 3, so one swizzled chunk serves both */          \
+        __bf16 *wd = base + 2 * PLANE + wr * RS + ((wq ^ ((wr >> 2) & 3)) << 3);                           \
+        *reinterpret_cast<bf16x8 *>(wd) = S_.wh0;                                                          \
+        *reinterpret_cast<bf16x8 *>(wd + 64 * RS) = S_.wh1;                                                \
+        *reinterpret_cast<bf16x8 *>(wd + PLANE) = S_.wl0;                                                  \
+        *reinterpret_cast<bf16x8 *>(wd + PLANE + 64 * RS) = S_.wl1;                                        \
+    }
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    if (a.colQ) {
+        const int hh = lane >> 5, jj = lane & 31;
+        const int c0 = col0 + wn * 64 + jj, c1 = c0 + 32;
+        const float wz0 = a.colwz ? a.colwz[c0] : 0.f, wz1 = a.colwz ? a.colwz[c1] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t rowA = row0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh, rowB = rowA + 32;
+            const int ciA = a.colidx[rowA], ciB = a.colidx[rowB];
+            const float zA = a.zf[rowA], zB = a.zf[rowB];
+            const float *qA = a.colQ + (size_t)ciA * a.ldq + a.qoff, *qB = a.colQ + (size_t)ciB * a.ldq + a.qoff;
+            acc00[r] = fmaf(wz0, zA, qA[c0]);
+            acc01[r] = fmaf(wz1, zA, qA[c1]);
+            acc10[r] = fmaf(wz0, zB, qB[c0]);
+            acc11[r] = fmaf(wz1, zB, qB[c1]);
+        }
+    }
+
+    // lane (r = lane & 31, h = lane >> 5): operand = 8 consecutive k (8h .. 8h+7) of row r inside a 16-wide k block
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, fh = lane >> 5;   // rows r and r + 32 / + 64 share the swizzle
+    const int fo0 = frow * RS + (((0 + fh) ^ fsw) << 3), fo1 = frow * RS + (((2 + fh) ^ fsw) << 3);
+#define BF3_COMPUTE(buf_)                                                                                  \
+    {                                                                                                      \
+        const __bf16 *T = lds + (buf_) * 4 * PLANE;                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                 \
+            const int fo = kb == 0 ? fo0 : fo1;                                                            \
+            const __bf16 *Ah = T + (wm * 64) * RS + fo, *Al = Ah + PLANE;                                  \
+            const __bf16 *Bh = T + 2 * PLANE + (wn * 64) * RS + fo, *Bl = Bh + PLANE;                      \
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(Ah), ah1 = *reinterpret_cast<const bf16x8 *>(Ah + 32 * RS); \
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(Al), al1 = *reinterpret_cast<const bf16x8 *>(Al + 32 * RS); \
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bh), bh1 = *reinterpret_cast<const bf16x8 *>(Bh + 32 * RS); \
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(Bl), bl1 = *reinterpret_cast<const bf16x8 *>(Bl + 32 * RS); \
+            /* small terms first, the dominant hi*hi product last */                                       \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);                     \
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);                     \
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);                     \
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);                     \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);                     \
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);                     \
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);                     \
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);                     \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);                     \
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);                     \
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);                     \
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);                     \
+        }                                                                                                  \
+    }
+    // step t: issue the loads of step t+2 (into the set step t used), compute step t, stage step t+1 (other set)
+#define BF3_STAMP(slot_)                                                                                   \
+    if (a.stamps) {                                                                                        \
+        unsigned long long ts_;                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (tid == 0 && blockIdx.x < 64 && t < 40) a.stamps[((size_t)blockIdx.x * 40 + t) * 4 + (slot_)] = ts_; \
+    }
+#define BF3_STEP(t_, SC_, SN_)                                                                             \
+    {                                                                                                      \
+        const int t = (t_);                                                                                \
+        BF3_STAMP(0)                                                                                       \
+        if (t + 2 < nsteps) BF3_GLOAD(SC_, t + 2)                                                          \
+        BF3_STAMP(1)                                                                                       \
+        BF3_COMPUTE(t & 1)                                                                                 \
+        BF3_STAMP(2)                                                                                       \
+        if (t + 1 < nsteps) BF3_LSTORE(SN_, (t + 1) & 1)                                                   \
+        BF3_STAMP(3)                                                                                       \
+        __syncthreads();                                                                                   \
+    }
+
+    BF3_GLOAD(S0, 0)
+    if (nsteps > 1) BF3_GLOAD(S1, 1)
+    BF3_LSTORE(S0, 0)
+    __syncthreads();
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        BF3_STEP(step, S0, S1)
+        BF3_STEP(step + 1, S1, S0)
+    }
+    if (step < nsteps) BF3_STEP(step, S0, S1)
+
+    const int h = lane >> 5, j = lane & 31;
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = col0 + wn * 64 + nt * 32 + j;
+        const float bias = a.bias[col];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[r] + bias;
+                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
+                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
+            }
+        }
+        if (a.partial) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (lane < 32) {
+                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
+                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
+            }
+        }
+    }
+    if (a.partial) {
+        __syncthreads();
+        if (tid < BN)
+            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_norm_finalize: (sum, sum^2) partials -> per-(chunk, channel) scale/shift of the following norm.
 // One wave per (chunk, group); double accumulation in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
@@ -1407,6 +1663,8 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
     return PIFU_OK;
 }
 
+static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st);
+
 static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g, int64_t rows, const uint8_t *mask,
                         int mask_bit, float *pred_out, int upto_layer /* exclusive; nlayers for all */, hipStream_t st)
 {
@@ -1475,6 +1733,13 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 ctx->prof_used += 2;
                 PIFU_HIP(hipEventRecord(e0, st));
             }
+            if (ctx->precision == 1) {
+                if (!table_ok) a.nsteps = 0;
+                int rc2 = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
+                if (rc2) return rc2;
+                a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
+                hipLaunchKernelGGL(k_mlp_gemm_bf3, dim3(nblocks), dim3(256), 0, st, a);
+            } else
             switch (ctx->gemm_variant) {
             case 1: hipLaunchKernelGGL((k_mlp_gemm<32, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 2: hipLaunchKernelGGL((k_mlp_gemm<16, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
@@ -1612,9 +1877,53 @@ static int prof_begin(pifu_ctx *ctx, hipStream_t st, hipEvent_t *e1)
     return PIFU_OK;
 }
 
+// bf16 hi / lo planes of a packed fp32 weight matrix, built on the device the first time the matrix is used
+static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st)
+{
+    auto it = ctx->bf16_planes.find((const void *)W);
+    if (it == ctx->bf16_planes.end() || it->second.n != n) {
+        if (it != ctx->bf16_planes.end()) { (void)hipFree(it->second.hi); ctx->bf16_planes.erase(it); }
+        void *p = nullptr;
+        PIFU_HIP(hipMalloc(&p, n * 2 * sizeof(__bf16)));
+        pifu_ctx::Planes pl{p, (char *)p + n * sizeof(__bf16), n};
+        hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, (__bf16 *)pl.hi, (__bf16 *)pl.lo, n);
+        it = ctx->bf16_planes.emplace((const void *)W, pl).first;
+    }
+    *hi = (const __bf16 *)it->second.hi;
+    *lo = (const __bf16 *)it->second.lo;
+    return PIFU_OK;
+}
+
+// per-K-step descriptor table (see GemmArgs::StepDesc); nsteps = 0 tells the kernels to use the segment selects instead
+static void fill_step_table(GemmArgs &a, int64_t rows)
+{
+    a.nsteps = 0;
+    int n = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi)
+        for (int k0 = 0; k0 < a.seg[sgi].width; k0 += BK, ++n) {
+            if (n >= 40 || (size_t)rows * a.seg[sgi].ld * 4 >= ((size_t)1 << 32) || a.seg[sgi].ld * 4 >= (1 << 24) || rows >= (1 << 24)) return;
+            GemmArgs::StepDesc &d = a.steps[n];
+            d.ptr = a.seg[sgi].ptr + k0; d.scale = a.seg[sgi].scale + k0; d.shift = a.seg[sgi].shift + k0;
+            d.ld4 = a.seg[sgi].ld * 4; d.sld = a.seg[sgi].sld; d.mode = a.seg[sgi].mode;
+        }
+    if ((size_t)a.ntn * BN * a.ldw * 2 >= ((size_t)1 << 32)) return;
+    a.nsteps = n;
+}
+
 static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
 {
     const int nblocks = (int)round_up(a.ntm, 8) * a.ntn;
+    fill_step_table(a, (int64_t)a.ntm * BM);
+    if (ctx->precision == 1) {
+        int rc = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
+        if (rc) return rc;
+        hipEvent_t e1b;
+        rc = prof_begin(ctx, st, &e1b);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_mlp_gemm_bf3, dim3(nblocks), dim3(256), 0, st, a);
+        if (e1b) { PIFU_HIP(hipEventRecord(e1b, st)); ctx->prof_flops += flops; ctx->prof_launches += 1; }
+        return PIFU_OK;
+    }
     hipEvent_t e1;
     int rc = prof_begin(ctx, st, &e1);
     if (rc) return rc;

@@ -160,3 +160,30 @@ def test_empty_and_bad_arguments():
                   _stream_ptr(netMR.device))
     with pytest.raises(RuntimeError):
         netMR.calc_normal(pts[:, None, :, :0], calib_tensor()[:, None], calib_tensor())      # SURVEY C-6
+
+
+def test_split_precision_bf16x3_within_contract(gold):
+    """Opt-in bf16 x 3 GEMMs (pifu_set_precision(ctx, 1)): occupancy still within the 1e-4 contract of the reference's
+    golden vectors (observed ~1e-5), and the exact-fp32 default is restored afterwards."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build()
+    calib = calib_tensor()
+    netMR.query(seeded_points(3, 700), calib)
+    exact = netMR.get_preds()[0, 0].cpu().numpy()
+    _lib.call('pifu_set_precision', netMR._ctx.h, 1)
+    try:
+        netMR.query(seeded_points(3, 700), calib)
+        split = netMR.get_preds()[0, 0].cpu().numpy()
+        assert np.abs(split - gold['group_a_fine']).max() < TOL
+        assert np.abs(netG.preds[0, 0].cpu().numpy() - gold['group_a_coarse']).max() < TOL
+        assert 0 < np.abs(split - exact).max() < TOL          # really a different arithmetic
+        pts = seeded_points(4, 1200, lim=1.0)
+        out = []
+        for s in range(0, 1200, 500):
+            netMR.query(pts[:, :, s:s + 500], calib)
+            out.append(netMR.get_preds()[0, 0].cpu().numpy())
+        assert np.abs(np.concatenate(out) - gold['group_b_fine']).max() < TOL
+    finally:
+        _lib.call('pifu_set_precision', netMR._ctx.h, 0)
+    netMR.query(seeded_points(3, 700), calib)
+    assert np.array_equal(netMR.get_preds()[0, 0].cpu().numpy(), exact)

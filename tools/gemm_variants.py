@@ -16,7 +16,8 @@ fc = torch.randn(1, 256, 128, 128, generator=g); ff = torch.randn(1, 16, 512, 51
 calib = torch.eye(4)[None]; calib[0, 1, 1] = -1
 built = {}
 for v in variants:
-    os.environ['PIFU_GEMM_VARIANT'] = str(v)
+    os.environ['PIFU_GEMM_VARIANT'] = str(v % 100)
+    os.environ['PIFU_PRECISION'] = '1' if v >= 100 else '0'      # 100 + variant = bf16x3 split precision
     netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda'); netMR = nets.PIFuMRNet(of, netG); netG.eval()
     netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}; netG._push_weights()
     netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}; netMR._push_weights()
