@@ -24,7 +24,11 @@ def test_gen_mesh_end_to_end(tmp_path):
     synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
     path = str(tmp_path / 'mesh.obj')
     timings = {}
-    verts, faces, color = reconstruction.gen_mesh(48, netMR, 'cuda', data, path, timings=timings)
+    # like the reference, an octree grid below init_resolution = 64 evaluates nothing, marching cubes fails,
+    # reconstruction() returns -1 and the tuple-unpack raises TypeError (mesh_util.py:138-140,94-96; reconstruction.py:56)
+    with pytest.raises(TypeError):
+        reconstruction.gen_mesh(48, netMR, 'cuda', data, path)
+    verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, timings=timings)
     assert os.path.exists(path) and os.path.exists(path[:-4] + '.png')
     assert len(verts) > 100 and len(faces) > 100 and timings['n_verts'] == len(verts)
     # reference quirk (SURVEY C-6): the last vertex is never coloured
@@ -42,7 +46,7 @@ def test_gen_mesh_end_to_end(tmp_path):
     assert np.median(cos) > 0.999 and (cos > 0.98).mean() > 0.9
     # mesh = marching cubes of the device SDF: faces bit-exact vs the serial oracle on the same field
     from pifuhd_amd import mesh_util
-    res = mesh_util.reconstruction(netMR, 'cuda', data['calib'], 48, None, None, 0.5, use_octree=True, num_samples=5000,
+    res = mesh_util.reconstruction(netMR, 'cuda', data['calib'], 64, None, None, 0.5, use_octree=True, num_samples=5000,
                                    return_sdf=True)
     v2, f2, _, _, sdf = res
     assert np.array_equal(f2, faces) and np.array_equal(v2, verts)
@@ -53,7 +57,7 @@ def test_gen_mesh_end_to_end(tmp_path):
         with torch.no_grad():
             return ref.query(torch.from_numpy(points[None]).float(), data['calib'])[0, 0].numpy()
     calib_inv = np.linalg.inv(data['calib'][0].numpy().astype(np.float64))
-    sdf_ref = O.eval_grid_octree(48, calib_inv, eval_func, 5000)
+    sdf_ref = O.eval_grid_octree(64, calib_inv, eval_func, 5000)
     assert np.abs(sdf.cpu().numpy() - sdf_ref).max() < 1e-4
 
 
