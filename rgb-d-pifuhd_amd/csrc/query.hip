@@ -1199,30 +1199,37 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
 __global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int groups, const float *gamma,
                                 const float *beta, float *scale, float *shift, ChunkGeom g, float eps, int halves)
 {
-    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // one 256-thread block per (chunk, group): a 200 000-point calc_normal chunk has 1 563 tiles x 32 channels per group,
+    // too many partials for a single wave.  Fixed summation order (strided per thread, then a fixed LDS tree).
+    __shared__ double shs[256], shq[256];
+    const int wid = blockIdx.x;
     if (wid >= g.nchunks * groups) return;
     const int c = wid / groups, grp = wid % groups;
     const int len = chunk_len(g, c);
     const int ntile = (len + BM - 1) / BM;
     double s = 0.0, q = 0.0;
     const int total = ntile * halves * cpg;       // `halves` partial rows per 128-row tile (2 for k_mlp_gemm_ws)
-    for (int i = lane; i < total; i += 64) {
+    for (int i = threadIdx.x; i < total; i += 256) {
         const int t = i / cpg, ch = grp * cpg + i % cpg;
         const float2 p = partial[(size_t)(c * g.tpc * halves + t) * ld + ch];
         s += (double)p.x;
         q += (double)p.y;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        q += __shfl_xor(q, o);
+    shs[threadIdx.x] = s;
+    shq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { shs[threadIdx.x] += shs[threadIdx.x + o]; shq[threadIdx.x] += shq[threadIdx.x + o]; }
+        __syncthreads();
     }
+    s = shs[0];
+    q = shq[0];
     const double cnt = (double)len * cpg;
     const double mean = s / cnt;
     double var = q / cnt - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int i = lane; i < cpg; i += 64) {
+    for (int i = threadIdx.x; i < cpg; i += 256) {
         const int ch = grp * cpg + i;
         const double gm = gamma[ch];
         scale[(size_t)c * ld + ch] = (float)(gm * rstd);
@@ -1766,7 +1773,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                 const int cpg = l.cout / groups;
                 const int nw = g.nchunks * groups;
-                hipLaunchKernelGGL(k_norm_finalize, dim3((nw + 3) / 4), dim3(256), 0, st, (const float2 *)b.partial[i],
+                hipLaunchKernelGGL(k_norm_finalize, dim3(nw), dim3(256), 0, st, (const float2 *)b.partial[i],
                                    l.cout_pad, cpg, groups, (const float *)l.gamma, (const float *)l.beta, b.scale[i],
                                    b.shift[i], g, 1e-5f, ctx->gemm_variant == 8 ? 2 : 1);
             }
@@ -2028,7 +2035,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                 const int cpg = l.cout / groups;
                 const int nw = g.nchunks * groups;
-                hipLaunchKernelGGL(k_norm_finalize, dim3((nw + 3) / 4), dim3(256), 0, st, (const float2 *)b.partial[i],
+                hipLaunchKernelGGL(k_norm_finalize, dim3(nw), dim3(256), 0, st, (const float2 *)b.partial[i],
                                    l.cout_pad, cpg, groups, (const float *)l.gamma, (const float *)l.beta, b.scale[i],
                                    b.shift[i], g, 1e-5f, 1);
             }

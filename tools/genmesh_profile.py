@@ -1,0 +1,23 @@
+import sys, time, tempfile, os
+sys.path.insert(0, '.')
+import numpy as np, torch
+import pifuhd_amd
+from pifuhd_amd import config, nets, synth, reconstruction as recon, mesh_util
+oc = config.coarse_opt(); of = config.fine_opt(oc)
+sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+data = synth.synthetic_inputs(1024, 3, seed=0)
+netMR.filter_global(data['img_512'].cuda()); netMR.filter_local(data['img'].cuda()[:, None])
+synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3)
+with tempfile.TemporaryDirectory() as td:
+    recon.gen_mesh(128, netMR, 'cuda', data, os.path.join(td, 'w.obj'))
+    for _ in range(2):
+        t = {}
+        recon.gen_mesh(512, netMR, 'cuda', data, os.path.join(td, 'm.obj'), timings=t)
+        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()}, flush=True)
+    # finer breakdown of reconstruction()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sdf, n = mesh_util.eval_grid_device(netMR, data['calib'], 512, 5000, True); torch.cuda.synchronize(); t1 = time.perf_counter()
+    v, f = mesh_util.marching_cubes_device(netMR._ctx, sdf, 0.5); torch.cuda.synchronize(); t2 = time.perf_counter()
+    vh = v.cpu().numpy(); fh = f.cpu().numpy(); t3 = time.perf_counter()
+    print('octree eval %.3f s (%d points evaluated = %.1f%% of grid), MC %.3f s, D2H %.3f s' % (t1 - t0, n, 100.0 * n / 512 ** 3, t2 - t1, t3 - t2))
