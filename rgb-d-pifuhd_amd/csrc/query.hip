@@ -342,600 +342,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_v2: k_mlp_gemm<32> with a leaner non-MFMA path.  On gfx950 the fp32 MFMA runs on the SIMD's vector
-// ALUs (it IS the fp32 vector rate), so every VALU/SALU instruction of the staging path is time the matrix
-// stream does not get.  Changes: (1) per-step descriptors from the kernarg table (scalar loads) replace the
-// segment select chain; (2) operand addresses are uniform base + 32-bit per-lane byte offset (saddr form, one
-// v_mad_u32_u24 per row instead of 64-bit pointer arithmetic); (3) raw segments skip the transform (uniform
-// branch).  Same tiles, same k order, bit-identical results.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm_v2(const GemmArgs a)
-{
-    constexpr int TBK = 32;
-    constexpr int LD = TBK + 4;
-    constexpr int TILE = BM * LD;
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile_n = slot % a.ntn;
-    const int tile_m = (slot / a.ntn) * 8 + xcd;
-    if (tile_m >= a.ntm) return;
-    const int chunk_id = tile_m / a.g.tpc;
-    const int col0 = tile_n * BN;
-    const int kq = tid & 7, sr = tid >> 3;
-    const int nsteps = a.nsteps;
-
-    // per-lane constants: rows staged by this thread, byte offsets into W (the same every step)
-    const unsigned r0 = tile_m * BM + sr, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
-    const unsigned kb = kq * 16;
-    const unsigned ldw4 = a.ldw * 4;
-    const unsigned wo0 = (col0 + sr) * ldw4 + kb, wo1 = wo0 + 32 * ldw4, wo2 = wo0 + 64 * ldw4, wo3 = wo0 + 96 * ldw4;
-
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
-    int rmode = 0;
-    rsc = rsh = make_float4(0, 0, 0, 0);
-
-    // descriptor of the step that the next V2_GLOAD will fetch, loaded one step early (its scalar-load latency
-    // would otherwise sit in front of every step's global loads)
-    const float *d_ptr = a.steps[0].ptr, *d_scale = a.steps[0].scale, *d_shift = a.steps[0].shift;
-    unsigned d_ld4 = a.steps[0].ld4;
-    int d_sld = a.steps[0].sld, d_mode = a.steps[0].mode;
-#define V2_GLOAD(step_)                                                                                    \
-    {                                                                                                      \
-        const char *ab = reinterpret_cast<const char *>(d_ptr);                                            \
-        const unsigned ld4 = d_ld4;                                                                        \
-        rmode = d_mode;                                                                                    \
-        ra0 = *reinterpret_cast<const float4 *>(ab + (__umul24(r0, ld4) + kb));                            \
-        ra1 = *reinterpret_cast<const float4 *>(ab + (__umul24(r1, ld4) + kb));                            \
-        ra2 = *reinterpret_cast<const float4 *>(ab + (__umul24(r2, ld4) + kb));                            \
-        ra3 = *reinterpret_cast<const float4 *>(ab + (__umul24(r3, ld4) + kb));                            \
-        if (rmode == 1) {                                                                                  \
-            const char *sb = reinterpret_cast<const char *>(d_scale + (size_t)chunk_id * d_sld);           \
-            const char *hb = reinterpret_cast<const char *>(d_shift + (size_t)chunk_id * d_sld);           \
-            rsc = *reinterpret_cast<const float4 *>(sb + kb);                                              \
-            rsh = *reinterpret_cast<const float4 *>(hb + kb);                                              \
-        }                                                                                                  \
-        const char *wb = reinterpret_cast<const char *>(a.W + (step_) * TBK);                              \
-        rw0 = *reinterpret_cast<const float4 *>(wb + wo0);                                                 \
-        rw1 = *reinterpret_cast<const float4 *>(wb + wo1);                                                 \
-        rw2 = *reinterpret_cast<const float4 *>(wb + wo2);                                                 \
-        rw3 = *reinterpret_cast<const float4 *>(wb + wo3);                                                 \
-        const int nx_ = (step_) + 1 < nsteps ? (step_) + 1 : (step_);                                      \
-        const GemmArgs::StepDesc &dn = a.steps[nx_];                                                       \
-        d_ptr = dn.ptr; d_scale = dn.scale; d_shift = dn.shift; d_ld4 = dn.ld4; d_sld = dn.sld; d_mode = dn.mode; \
-    }
-#define V2_XF(v_)                                                                                          \
-    {                                                                                                      \
-        float t_;                                                                                          \
-        t_ = fmaf(v_.x, rsc.x, rsh.x); v_.x = fmaxf(t_, 0.01f * t_);                                       \
-        t_ = fmaf(v_.y, rsc.y, rsh.y); v_.y = fmaxf(t_, 0.01f * t_);                                       \
-        t_ = fmaf(v_.z, rsc.z, rsh.z); v_.z = fmaxf(t_, 0.01f * t_);                                       \
-        t_ = fmaf(v_.w, rsc.w, rsh.w); v_.w = fmaxf(t_, 0.01f * t_);                                       \
-    }
-#define V2_LK(v_) { v_.x = fmaxf(v_.x, 0.01f * v_.x); v_.y = fmaxf(v_.y, 0.01f * v_.y); v_.z = fmaxf(v_.z, 0.01f * v_.z); v_.w = fmaxf(v_.w, 0.01f * v_.w); }
-#define V2_LSTORE(buf_)                                                                                    \
-    {                                                                                                      \
-        float *la = lds + (buf_) * 2 * TILE + sr * LD + kq * 4;                                            \
-        if (rmode == 1) { V2_XF(ra0) V2_XF(ra1) V2_XF(ra2) V2_XF(ra3) }                                    \
-        else if (rmode == 2) { V2_LK(ra0) V2_LK(ra1) V2_LK(ra2) V2_LK(ra3) }                               \
-        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
-        *reinterpret_cast<float4 *>(la + 32 * LD) = ra1;                                                   \
-        *reinterpret_cast<float4 *>(la + 64 * LD) = ra2;                                                   \
-        *reinterpret_cast<float4 *>(la + 96 * LD) = ra3;                                                   \
-        *reinterpret_cast<float4 *>(la + TILE) = rw0;                                                      \
-        *reinterpret_cast<float4 *>(la + TILE + 32 * LD) = rw1;                                            \
-        *reinterpret_cast<float4 *>(la + TILE + 64 * LD) = rw2;                                            \
-        *reinterpret_cast<float4 *>(la + TILE + 96 * LD) = rw3;                                            \
-    }
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    V2_GLOAD(0)
-    V2_LSTORE(0)
-    __syncthreads();
-    const int foffA = (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-    const int foffB = TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) V2_GLOAD(step + 1)
-        const float *T = lds + buf * 2 * TILE;
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int s = 0; s < TBK / 8; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(T + foffA + s * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(T + foffA + 32 * LD + s * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(T + foffB + s * 8);
-            const float4 b1v = *reinterpret_cast<const float4 *>(T + foffB + 32 * LD + s * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) V2_LSTORE(buf ^ 1)
-        __syncthreads();
-    }
-
-    const size_t row0 = (size_t)tile_m * BM;
-    const int h = lane >> 5, j = lane & 31;
-    const int local0 = (tile_m % a.g.tpc) * BM;
-    int nvalid = chunk_len(a.g, chunk_id) - local0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-    float *red = lds;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = col0 + wn * 64 + nt * 32 + j;
-        const float bias = a.bias[col];
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = acc[r] + bias;
-                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
-                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
-            }
-        }
-        if (a.partial) {
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (lane < 32) {
-                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
-                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
-            }
-        }
-    }
-    if (a.partial) {
-        __syncthreads();
-        if (tid < BN)
-            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
-                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_ring: same math and operand layout as k_mlp_gemm (bit-identical results), different pipeline.
-// Measured problem of the 2-buffer kernel (s_memtime stamps): a wave has a ~1 700-cycle MFMA-free
-// tail per K step (staging, barrier, next loads, first fragment reads) and the block barrier lines the two
-// resident blocks' tails up.  Here every wave keeps its own MFMA stream continuous:
-//   * 3-deep LDS ring: step t computes tile t, writes tile t+2 (loaded into registers one step earlier, so its
-//     vmcnt wait is already satisfied) and issues the global loads of tile t+3;
-//   * tile t+1 is stable during step t (published by the previous barrier), so its first fragments are read
-//     BEFORE the end-of-step barrier and the next step's MFMAs start right after it;
-//   * all non-MFMA work of a step is cut into chunks placed between the MFMA groups.
-// Two register sets hold the in-flight tiles (tile j uses set j & 1) => the step loop is unrolled by two.
-// ------------------------------------------------------------------------------------------------
-template <int TBK>
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm_ring(const GemmArgs a)
-{
-    constexpr int LD = TBK + 4;
-    constexpr int TILE = BM * LD;
-    constexpr int F4_PER_ROW = TBK / 4;
-    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
-    constexpr int NP = BM / ROWS_PER_PASS;   // 4 at BK 32, 2 at BK 16
-    constexpr int NS = TBK / 8;              // 4 or 2 MFMA groups (8 k each) per step
-    __shared__ __attribute__((aligned(16))) float lds[6 * TILE];   // ring of 3 x [A|B]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile_n = slot % a.ntn;
-    const int tile_m = (slot / a.ntn) * 8 + xcd;
-    if (tile_m >= a.ntm) return;
-    const int chunk_id = tile_m / a.g.tpc;
-    const size_t row0 = (size_t)tile_m * BM;
-    const int col0 = tile_n * BN;
-    const int kq = tid % F4_PER_ROW, sr = tid / F4_PER_ROW;
-    const int b1 = a.seg[0].width;
-    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
-    const int nsteps = a.ldw / TBK;
-
-    struct Stage { float4 a0, a1, a2, a3, w0, w1, w2, w3, sc, sh; float slope; };
-    Stage S0, S1;
-    S0.a2 = S0.a3 = S0.w2 = S0.w3 = S1.a2 = S1.a3 = S1.w2 = S1.w3 = make_float4(0, 0, 0, 0);
-    S0.slope = S1.slope = 1.f;
-
-#define RING_GLOAD(S_, step_)                                                                              \
-    {                                                                                                      \
-        const int kk = (step_) * TBK;                                                                      \
-        const int sg = (kk >= b1) + (kk >= b2);                                                            \
-        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
-        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
-        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
-        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
-        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
-        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
-        S_.slope = md == 0 ? 1.f : 0.01f;                                                                  \
-        const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
-        const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
-        S_.a0 = *reinterpret_cast<const float4 *>(ap);                                                     \
-        S_.a1 = *reinterpret_cast<const float4 *>(ap + (size_t)ROWS_PER_PASS * ld);                        \
-        if constexpr (NP > 2) {                                                                            \
-            S_.a2 = *reinterpret_cast<const float4 *>(ap + (size_t)2 * ROWS_PER_PASS * ld);                \
-            S_.a3 = *reinterpret_cast<const float4 *>(ap + (size_t)3 * ROWS_PER_PASS * ld);                \
-        }                                                                                                  \
-        S_.sc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                       \
-        S_.sh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                       \
-        const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                                 \
-        S_.w0 = *reinterpret_cast<const float4 *>(wp);                                                     \
-        S_.w1 = *reinterpret_cast<const float4 *>(wp + (size_t)ROWS_PER_PASS * a.ldw);                     \
-        if constexpr (NP > 2) {                                                                            \
-            S_.w2 = *reinterpret_cast<const float4 *>(wp + (size_t)2 * ROWS_PER_PASS * a.ldw);             \
-            S_.w3 = *reinterpret_cast<const float4 *>(wp + (size_t)3 * ROWS_PER_PASS * a.ldw);             \
-        }                                                                                                  \
-    }
-#define RING_ST1(S_, base_, p_, va_, vw_)                                                                  \
-    {                                                                                                      \
-        float *la = (base_) + (sr + (p_) * ROWS_PER_PASS) * LD + kq * 4;                                   \
-        float4 v_ = S_.va_;                                                                                \
-        float t_;                                                                                          \
-        t_ = fmaf(v_.x, S_.sc.x, S_.sh.x); v_.x = fmaxf(t_, S_.slope * t_);                                \
-        t_ = fmaf(v_.y, S_.sc.y, S_.sh.y); v_.y = fmaxf(t_, S_.slope * t_);                                \
-        t_ = fmaf(v_.z, S_.sc.z, S_.sh.z); v_.z = fmaxf(t_, S_.slope * t_);                                \
-        t_ = fmaf(v_.w, S_.sc.w, S_.sh.w); v_.w = fmaxf(t_, S_.slope * t_);                                \
-        *reinterpret_cast<float4 *>(la) = v_;                                                              \
-        *reinterpret_cast<float4 *>(la + TILE) = S_.vw_;                                                   \
-    }
-#define RING_STORE_H0(S_, base_)                                                                           \
-    {                                                                                                      \
-        RING_ST1(S_, base_, 0, a0, w0)                                                                     \
-        if constexpr (NP > 2) RING_ST1(S_, base_, 1, a1, w1)                                               \
-    }
-#define RING_STORE_H1(S_, base_)                                                                           \
-    {                                                                                                      \
-        if constexpr (NP > 2) {                                                                            \
-            RING_ST1(S_, base_, 2, a2, w2)                                                                 \
-            RING_ST1(S_, base_, 3, a3, w3)                                                                 \
-        } else {                                                                                           \
-            RING_ST1(S_, base_, 1, a1, w1)                                                                 \
-        }                                                                                                  \
-    }
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    struct Frag { float4 a0, a1, b0, b1; };
-    Frag F0, F1;
-    const int foffA = (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-    const int foffB = TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-
-#define RING_FRAG(F_, base_, s_)                                                                           \
-    {                                                                                                      \
-        F_.a0 = *reinterpret_cast<const float4 *>((base_) + foffA + (s_) * 8);                             \
-        F_.a1 = *reinterpret_cast<const float4 *>((base_) + foffA + 32 * LD + (s_) * 8);                   \
-        F_.b0 = *reinterpret_cast<const float4 *>((base_) + foffB + (s_) * 8);                             \
-        F_.b1 = *reinterpret_cast<const float4 *>((base_) + foffB + 32 * LD + (s_) * 8);                   \
-    }
-#define RING_MFMA1(av0_, av1_, bv0_, bv1_)                                                                 \
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv0_, acc00, 0, 0, 0);                              \
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv1_, acc01, 0, 0, 0);                              \
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv0_, acc10, 0, 0, 0);                              \
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv1_, acc11, 0, 0, 0);
-#define RING_MFMA_FIRST(F_) RING_MFMA1(F_.a0.x, F_.a1.x, F_.b0.x, F_.b1.x)
-#define RING_MFMA_REST(F_)                                                                                 \
-    RING_MFMA1(F_.a0.y, F_.a1.y, F_.b0.y, F_.b1.y)                                                         \
-    RING_MFMA1(F_.a0.z, F_.a1.z, F_.b0.z, F_.b1.z)                                                         \
-    RING_MFMA1(F_.a0.w, F_.a1.w, F_.b0.w, F_.b1.w)
-
-    // one K step.  SW_ = register set holding tile t+2 (written now), SL_ = set that receives tile t+3.
-#define RING_STEP(t_, SW_, SL_)                                                                            \
-    {                                                                                                      \
-        const int t = (t_);                                                                                \
-        float *cur = lds + (t % 3) * 2 * TILE;                                                             \
-        float *nxt = lds + ((t + 1) % 3) * 2 * TILE;                                                       \
-        float *wrt = lds + ((t + 2) % 3) * 2 * TILE;                                                       \
-        const bool has1 = t + 1 < nsteps, has2 = t + 2 < nsteps, has3 = t + 3 < nsteps;                    \
-        /* group 0 (fragments already in F0) */                                                            \
-        RING_FRAG(F1, cur, 1)                                                                              \
-        RING_MFMA_FIRST(F0)                                                                                \
-        if (has3) RING_GLOAD(SL_, t + 3)                                                                   \
-        RING_MFMA_REST(F0)                                                                                 \
-        if constexpr (NS == 2) {                                                                           \
-            if (has1) RING_FRAG(F0, nxt, 0)                                                                \
-            RING_MFMA_FIRST(F1)                                                                            \
-            if (has2) { RING_STORE_H0(SW_, wrt) RING_STORE_H1(SW_, wrt) }                                  \
-            RING_MFMA_REST(F1)                                                                             \
-        } else {                                                                                           \
-            RING_FRAG(F0, cur, 2)                                                                          \
-            RING_MFMA_FIRST(F1)                                                                            \
-            if (has2) RING_STORE_H0(SW_, wrt)                                                              \
-            RING_MFMA_REST(F1)                                                                             \
-            RING_FRAG(F1, cur, 3)                                                                          \
-            RING_MFMA_FIRST(F0)                                                                            \
-            if (has2) RING_STORE_H1(SW_, wrt)                                                              \
-            RING_MFMA_REST(F0)                                                                             \
-            if (has1) RING_FRAG(F0, nxt, 0)                                                                \
-            RING_MFMA_FIRST(F1)                                                                            \
-            RING_MFMA_REST(F1)                                                                             \
-        }                                                                                                  \
-        __syncthreads();                                                                                   \
-    }
-
-    // ---- prologue: tiles 0 and 1 into the ring, tile 2 in flight, first fragments in registers
-    RING_GLOAD(S0, 0)
-    if (nsteps > 1) RING_GLOAD(S1, 1)
-    { float *b0p = lds; RING_STORE_H0(S0, b0p) RING_STORE_H1(S0, b0p) }
-    if (nsteps > 1) { float *b1p = lds + 2 * TILE; RING_STORE_H0(S1, b1p) RING_STORE_H1(S1, b1p) }
-    if (nsteps > 2) RING_GLOAD(S0, 2)
-    __syncthreads();
-    RING_FRAG(F0, lds, 0)
-
-    __builtin_amdgcn_s_setprio(3);
-    int step = 0;
-    for (; step + 1 < nsteps; step += 2) {
-        RING_STEP(step, S0, S1)
-        RING_STEP(step + 1, S1, S0)
-    }
-    if (step < nsteps) RING_STEP(step, S0, S1)
-    __builtin_amdgcn_s_setprio(0);
-
-    // ---- epilogue (identical to k_mlp_gemm)
-    const int h = lane >> 5, j = lane & 31;
-    const int local0 = (tile_m % a.g.tpc) * BM;
-    int nvalid = chunk_len(a.g, chunk_id) - local0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-    float *red = lds;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = col0 + wn * 64 + nt * 32 + j;
-        const float bias = a.bias[col];
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = acc[r] + bias;
-                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
-                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
-            }
-        }
-        if (a.partial) {
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (lane < 32) {
-                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
-                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
-            }
-        }
-    }
-    if (a.partial) {
-        __syncthreads();
-        if (tid < BN)
-            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
-                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_ws: wave-specialised, persistent version of the MLP GEMM (same tiles, same k order, same fused
-// prologue / epilogue).  Why: stamps of k_mlp_gemm show a ~1 700-cycle MFMA-free tail per K step per wave
-// (staging, barrier, next-tile loads, first fragment reads) that the second resident block does not hide
-// (the older wave wins every matrix-pipe arbitration and the block barrier lines the tails up).  Here
-//   * waves 0-3 (one per SIMD) only read fragments and issue MFMAs: 64 MFMAs + 16 ds_read_b128 + one
-//     barrier per K step; the first fragments of the next step are read before the barrier (that tile is
-//     already published), so the MFMA stream continues right after it;
-//   * waves 4-7 (one per SIMD) run the whole operand pipeline into a 3-deep LDS ring: global loads three
-//     steps ahead (two register sets), norm + LeakyReLU transform, ds_write two steps ahead;
-//   * blocks are persistent (one per CU, 110 KB of LDS): the loaders run ahead across output-tile boundaries,
-//     so a tile's prologue overlaps the previous tile's epilogue.
-// Both roles execute exactly one barrier per K step (+1 at start), so the counts always match.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void k_mlp_gemm_ws(const GemmArgs a)
-{
-    constexpr int TBK = 32;
-    constexpr int LD = TBK + 4;
-    constexpr int TILE = BM * LD;
-    __shared__ __attribute__((aligned(16))) float lds[6 * TILE];   // ring of 3 x [A|B] = 110,592 B
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int nsteps = a.ldw / TBK;
-    const int nq = ((a.ntm + 7) / 8) * 8 * a.ntn;        // padded tile count (XCD-aware enumeration)
-    const int b1 = a.seg[0].width;
-    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
-
-    // enumeration of this block's tiles: q = blockIdx.x + it * gridDim.x; same (b % 8)-label trick as k_mlp_gemm
-    auto tile_of = [&](int it, int &tile_m, int &tile_n) -> bool {
-        const int q = blockIdx.x + it * gridDim.x;
-        if (q >= nq) return false;
-        const int xcd = q & 7, slot = q >> 3;
-        tile_n = slot % a.ntn;
-        tile_m = (slot / a.ntn) * 8 + xcd;
-        return true;
-    };
-    int ntiles = 0;
-    for (int it = 0;; ++it) {
-        int tm, tn;
-        if (!tile_of(it, tm, tn)) break;
-        if (tm < a.ntm) ++ntiles;
-    }
-    const int G = ntiles * nsteps;           // global K steps of this block
-    if (G == 0) return;
-
-#define WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-    if (wave >= 4) {
-        // =========================== loaders ===========================
-        // raised priority: a loader instruction that is ready issues ahead of the co-resident consumer's MFMAs
-        // (at equal priority the older consumer wave wins every arbitration and the loaders starve: 6 700-cycle steps)
-        __builtin_amdgcn_s_setprio(3);
-        const int ltid = tid - 256;
-        const int kq = ltid & 7, sr = ltid >> 3;
-        struct Stage { float4 a0, a1, a2, a3, w0, w1, w2, w3, sc, sh; float slope; };
-        Stage S0, S1;
-        S0.slope = S1.slope = 1.f;
-        // load cursor
-        int it = -1, tile_m = 0, tile_n = 0, kstep = nsteps, loaded = 0;
-        size_t row0 = 0;
-        int col0 = 0, chunk_id = 0;
-        auto advance = [&]() {            // move the cursor to the next global step (if any)
-            if (++kstep >= nsteps) {
-                kstep = 0;
-                do { ++it; } while (tile_of(it, tile_m, tile_n) && tile_m >= a.ntm);
-                row0 = (size_t)tile_m * BM;
-                col0 = tile_n * BN;
-                chunk_id = tile_m / a.g.tpc;
-            }
-        };
-#define WS_GLOAD(S_)                                                                                       \
-        {                                                                                                  \
-            const int kk = kstep * TBK;                                                                    \
-            const int sg = (kk >= b1) + (kk >= b2);                                                        \
-            const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);           \
-            const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);      \
-            const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);      \
-            const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                  \
-            const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);              \
-            const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);            \
-            S_.slope = md == 0 ? 1.f : 0.01f;                                                              \
-            const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                              \
-            const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                         \
-            S_.a0 = *reinterpret_cast<const float4 *>(ap);                                                 \
-            S_.a1 = *reinterpret_cast<const float4 *>(ap + (size_t)32 * ld);                               \
-            S_.a2 = *reinterpret_cast<const float4 *>(ap + (size_t)64 * ld);                               \
-            S_.a3 = *reinterpret_cast<const float4 *>(ap + (size_t)96 * ld);                               \
-            S_.sc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                   \
-            S_.sh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                   \
-            const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                             \
-            S_.w0 = *reinterpret_cast<const float4 *>(wp);                                                 \
-            S_.w1 = *reinterpret_cast<const float4 *>(wp + (size_t)32 * a.ldw);                            \
-            S_.w2 = *reinterpret_cast<const float4 *>(wp + (size_t)64 * a.ldw);                            \
-            S_.w3 = *reinterpret_cast<const float4 *>(wp + (size_t)96 * a.ldw);                            \
-        }
-#define WS_ST1(S_, base_, p_, va_, vw_)                                                                    \
-        {                                                                                                  \
-            float *la = (base_) + (sr + (p_) * 32) * LD + kq * 4;                                          \
-            float4 v_ = S_.va_;                                                                            \
-            float t_;                                                                                      \
-            t_ = fmaf(v_.x, S_.sc.x, S_.sh.x); v_.x = fmaxf(t_, S_.slope * t_);                            \
-            t_ = fmaf(v_.y, S_.sc.y, S_.sh.y); v_.y = fmaxf(t_, S_.slope * t_);                            \
-            t_ = fmaf(v_.z, S_.sc.z, S_.sh.z); v_.z = fmaxf(t_, S_.slope * t_);                            \
-            t_ = fmaf(v_.w, S_.sc.w, S_.sh.w); v_.w = fmaxf(t_, S_.slope * t_);                            \
-            *reinterpret_cast<float4 *>(la) = v_;                                                          \
-            *reinterpret_cast<float4 *>(la + TILE) = S_.vw_;                                               \
-        }
-#define WS_STORE(S_, base_)                                                                                \
-        { WS_ST1(S_, base_, 0, a0, w0) WS_ST1(S_, base_, 1, a1, w1) WS_ST1(S_, base_, 2, a2, w2) WS_ST1(S_, base_, 3, a3, w3) }
-        // loads step `loaded` into the set of its parity, if it exists
-#define WS_LOAD_NEXT(S_)                                                                                   \
-        if (loaded < G) { advance(); WS_GLOAD(S_) ++loaded; }
-
-        // prologue: steps 0 and 1 into the ring, step 2 in flight
-        WS_LOAD_NEXT(S0)
-        WS_LOAD_NEXT(S1)
-        { float *bp = lds; WS_STORE(S0, bp) }
-        if (G > 1) { float *bp = lds + 2 * TILE; WS_STORE(S1, bp) }
-        WS_LOAD_NEXT(S0)
-        WS_BARRIER();
-        for (int g = 0; g < G; g += 2) {
-            {   // slot g (even): write step g+2 (set 0), load step g+3 (set 1)
-                float *wrt = lds + ((g + 2) % 3) * 2 * TILE;
-                WS_LOAD_NEXT(S1)
-                if (g + 2 < G) WS_STORE(S0, wrt)
-                WS_BARRIER();
-            }
-            if (g + 1 < G) {   // slot g+1 (odd): write step g+3 (set 1), load step g+4 (set 0)
-                float *wrt = lds + ((g + 3) % 3) * 2 * TILE;
-                WS_LOAD_NEXT(S0)
-                if (g + 3 < G) WS_STORE(S1, wrt)
-                WS_BARRIER();
-            }
-        }
-        return;
-    }
-
-    // =========================== consumers ===========================
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    struct Frag { float4 a0, a1, b0, b1; };
-    Frag F0, F1;
-    const int foffA = (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-    const int foffB = TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-#define WS_FRAG(F_, base_, s_)                                                                             \
-    {                                                                                                      \
-        F_.a0 = *reinterpret_cast<const float4 *>((base_) + foffA + (s_) * 8);                             \
-        F_.a1 = *reinterpret_cast<const float4 *>((base_) + foffA + 32 * LD + (s_) * 8);                   \
-        F_.b0 = *reinterpret_cast<const float4 *>((base_) + foffB + (s_) * 8);                             \
-        F_.b1 = *reinterpret_cast<const float4 *>((base_) + foffB + 32 * LD + (s_) * 8);                   \
-    }
-#define WS_MFMA1(av0_, av1_, bv0_, bv1_)                                                                   \
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv0_, acc00, 0, 0, 0);                              \
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0_, bv1_, acc01, 0, 0, 0);                              \
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv0_, acc10, 0, 0, 0);                              \
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1_, bv1_, acc11, 0, 0, 0);
-#define WS_MFMA(F_)                                                                                        \
-    WS_MFMA1(F_.a0.x, F_.a1.x, F_.b0.x, F_.b1.x) WS_MFMA1(F_.a0.y, F_.a1.y, F_.b0.y, F_.b1.y)              \
-    WS_MFMA1(F_.a0.z, F_.a1.z, F_.b0.z, F_.b1.z) WS_MFMA1(F_.a0.w, F_.a1.w, F_.b0.w, F_.b1.w)
-
-    int it = -1, tile_m = 0, tile_n = 0;
-    auto next_tile = [&]() { do { ++it; } while (tile_of(it, tile_m, tile_n) && tile_m >= a.ntm); };
-    next_tile();
-    WS_BARRIER();                        // matches the loaders' prologue barrier: steps 0 and 1 are in the ring
-    WS_FRAG(F0, lds, 0)
-    int kstep = 0;
-    for (int g = 0; g < G; ++g) {
-        const float *cur = lds + (g % 3) * 2 * TILE;
-        const float *nxt = lds + ((g + 1) % 3) * 2 * TILE;
-        if (a.stamps && wave == 0 && lane == 0 && blockIdx.x < 64 && g < 40)
-            a.stamps[((size_t)blockIdx.x * 40 + g) * 4] = __builtin_amdgcn_s_memtime();
-        WS_FRAG(F1, cur, 1)
-        WS_MFMA(F0)
-        WS_FRAG(F0, cur, 2)
-        WS_MFMA(F1)
-        WS_FRAG(F1, cur, 3)
-        WS_MFMA(F0)
-        if (g + 1 < G) WS_FRAG(F0, nxt, 0)
-        WS_MFMA(F1)
-        asm volatile("s_barrier" ::: "memory");
-        if (++kstep == nsteps) {
-            // ---- tile epilogue: bias, raw store, per-column statistics of this wave's 64 rows
-            kstep = 0;
-            const int chunk_id = tile_m / a.g.tpc;
-            const size_t row0 = (size_t)tile_m * BM;
-            const int col0 = tile_n * BN;
-            const int h = lane >> 5, j = lane & 31;
-            const int local0 = (tile_m % a.g.tpc) * BM;
-            int nvalid = chunk_len(a.g, chunk_id) - local0;
-            nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int col = col0 + wn * 64 + nt * 32 + j;
-                const float bias = a.bias[col];
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const float v = acc[r] + bias;
-                        a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
-                        if (row < nvalid) { s += v; q = fmaf(v, v, q); }
-                    }
-                }
-                if (a.partial) {
-                    s += __shfl_xor(s, 32);
-                    q += __shfl_xor(q, 32);
-                    if (lane < 32) a.partial[((size_t)tile_m * 2 + wm) * a.ldy + col] = make_float2(s, q);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-            next_tile();
-        }
-    }
-}
+#ifdef PIFU_GEMM_EXPERIMENTS
+#include "gemm_experiments.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_mlp_gemm_bf3: opt-in split-precision version of the MLP GEMM on the bf16 matrix cores.
@@ -1000,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
     unsigned d_ld4 = a.steps[0].ld4;
     int d_sld = a.steps[0].sld, d_mode = a.steps[0].mode, d_next = 1;
 #define BF3_GLOAD(S_, step_)                                                                               \
+    {                                                                                                      \
     if (use_table) {                                                                                       \
         const char *ab = reinterpret_cast<const char *>(d_ptr);                                            \
         S_.slope = d_mode == 0 ? 1.f : 0.01f;                                                              \
@@ -1044,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
         S_.wh1 = *reinterpret_cast<const bf16x8 *>(a.Whi + wo + (size_t)64 * a.ldw);                       \
         S_.wl0 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo);                                            \
         S_.wl1 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo + (size_t)64 * a.ldw);                       \
+    }                                                                                                      \
     }
     // transform, split into hi / lo and write one float4 (4 k) of A
 #define BF3_STA(S_, base_, p_, va_)                                                                        \
@@ -1747,21 +1158,29 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
                 hipLaunchKernelGGL(k_mlp_gemm_bf3, dim3(nblocks), dim3(256), 0, st, a);
             } else
+            {
+#ifdef PIFU_GEMM_EXPERIMENTS
             switch (ctx->gemm_variant) {
+            case 0: hipLaunchKernelGGL((k_mlp_gemm<32, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 1: hipLaunchKernelGGL((k_mlp_gemm<32, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 2: hipLaunchKernelGGL((k_mlp_gemm<16, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 3: hipLaunchKernelGGL((k_mlp_gemm<16, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 4: hipLaunchKernelGGL((k_mlp_gemm<32, 3>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 5: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 6: hipLaunchKernelGGL((k_mlp_gemm_ring<16>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 7: hipLaunchKernelGGL((k_mlp_gemm_ring<32>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 8: a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr; hipLaunchKernelGGL(k_mlp_gemm_ws, dim3(ctx->num_cus), dim3(512), 0, st, a); break;
+            case 8: a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
+                    hipLaunchKernelGGL(k_mlp_gemm_ws, dim3(ctx->num_cus), dim3(512), 0, st, a); break;
+            case 9: a.stamps = (L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
+                    hipLaunchKernelGGL((k_mlp_gemm<32, 2>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 10: if (table_ok) { hipLaunchKernelGGL(k_mlp_gemm_v2, dim3(nblocks), dim3(256), 0, st, a); break; }
                      hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 11: hipLaunchKernelGGL((k_mlp_gemm<32, 5>), dim3(std::min(nblocks, 2 * ctx->num_cus)), dim3(256), 0, st, a); break;
-            case 9: a.stamps = (L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr; hipLaunchKernelGGL((k_mlp_gemm<32, 2>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 0: hipLaunchKernelGGL((k_mlp_gemm<32, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;   // MFMA phase at raised priority (+2 %)
+            default: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
+            }
+#else
+            (void)table_ok;
+            hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a);   // MFMA phase at s_setprio 3
+#endif
             }
             if (ctx->prof_on) {
                 PIFU_HIP(hipEventRecord(e1, st));
@@ -1775,7 +1194,13 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 const int nw = g.nchunks * groups;
                 hipLaunchKernelGGL(k_norm_finalize, dim3(nw), dim3(256), 0, st, (const float2 *)b.partial[i],
                                    l.cout_pad, cpg, groups, (const float *)l.gamma, (const float *)l.beta, b.scale[i],
-                                   b.shift[i], g, 1e-5f, ctx->gemm_variant == 8 ? 2 : 1);
+                                   b.shift[i], g, 1e-5f,
+#ifdef PIFU_GEMM_EXPERIMENTS
+                                   ctx->gemm_variant == 8 ? 2 : 1
+#else
+                                   1
+#endif
+                                   );
             }
         } else {
             if (!pred_out) continue;
