@@ -114,3 +114,43 @@ def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, th
             break
         reso //= 2
     return sdf, evaluated
+
+
+def shard_range(n_items: int, world_size: int, rank: int):
+    """Contiguous share [i0, i1) of `n_items` for `rank`, and the per-rank capacity."""
+    per = (n_items + world_size - 1) // world_size
+    i0 = min(rank * per, n_items)
+    return i0, min(i0 + per, n_items), per
+
+
+def sharded_calls(spans, call_fn, width, device, group=None):
+    """Shard a list of independent calls (each one GroupNorm batch, e.g. the 50 000-vertex `calc_normal`
+    calls of `gen_mesh`, `reconstruction.py:58-70`) across ranks by contiguous call ranges.
+
+    spans: list of (left, right) row ranges, ascending and disjoint; call_fn(left, right) -> float32 tensor
+    [right-left, width] on `device`.  Returns float32 [spans[-1][1], width] (rows outside every span are 0),
+    identical on every rank after ONE all-gather."""
+    import torch.distributed as dist
+    rank, ws = world()
+    n_rows = spans[-1][1] if spans else 0
+    out = torch.zeros(n_rows, width, device=device, dtype=torch.float32)
+    if ws == 1:
+        for (l, r) in spans:
+            out[l:r] = call_fn(l, r)
+        return out
+    i0, i1, per = shard_range(len(spans), ws, rank)
+    slot_rows = max(max((r - l) for (l, r) in spans), 1) * per
+    local = torch.zeros(slot_rows, width, device=device, dtype=torch.float32)
+    row = 0
+    for (l, r) in spans[i0:i1]:
+        local[row:row + (r - l)] = call_fn(l, r)
+        row += r - l
+    full = torch.empty(ws * slot_rows, width, device=device, dtype=torch.float32)
+    dist.all_gather_into_tensor(full, local, group=group)
+    for rk in range(ws):
+        j0, j1, _ = shard_range(len(spans), ws, rk)
+        row = rk * slot_rows
+        for (l, r) in spans[j0:j1]:
+            out[l:r] = full[row:row + (r - l)]
+            row += r - l
+    return out

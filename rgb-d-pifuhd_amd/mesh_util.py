@@ -87,15 +87,23 @@ def marching_cubes_device(ctx, volume, level):
 
 
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
-                   num_samples=10000, transform=None, return_sdf=False):
+                   num_samples=10000, transform=None, return_sdf=False, sharded=False):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
     values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
-    [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty."""
-    try:
-        ctx = _ctx_of(net)
+    [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty.
+    `sharded=True`: the grid evaluation is split over the ranks of the initialised process group
+    (`pifuhd_amd.dist`); every rank gets the identical field and runs marching cubes redundantly."""
+    ctx = _ctx_of(net)
+    from . import dist as pdist
+    if sharded and pdist.world()[1] > 1:
+        flags = _lib.Q_COARSE_ONLY if isinstance(net, PIFuNetwNML) else 0
+        R = int(resolution)
+        if use_octree:
+            sdf, _ = pdist.eval_grid_octree_sharded(net, calib_tensor, R, num_samples, flags=flags)
+        else:
+            sdf = pdist.eval_lattice_sharded(net, calib_tensor, (R, R, R), num_samples, flags).double().view(R, R, R)
+    else:
         sdf, _ = eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree)
-    except _lib.PifuError:
-        raise
     try:
         verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
         verts = verts_d.cpu().numpy()

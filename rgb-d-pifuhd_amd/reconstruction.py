@@ -30,9 +30,28 @@ def _save_debug_png(path, image_tensor_global):
     return True
 
 
-def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None):
-    """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`."""
+def _normal_spans(n_verts, interval=50000):
+    """The slices of the reference's colour loop (`reconstruction.py:58-70`): `interval`-vertex calls, the last
+    one ending at -1, so the last vertex is never coloured (SURVEY C-6)."""
+    spans = []
+    for i in range(n_verts // interval + 1):
+        left = i * interval
+        right = n_verts - 1 if i == n_verts // interval else (i + 1) * interval
+        spans.append((left, max(right, left)))
+    return spans
+
+
+def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None,
+             sharded=False):
+    """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.
+
+    `sharded=True` (not in the reference, which is single-device): every rank of the initialised
+    `torch.distributed` group calls gen_mesh with the SAME data; grid evaluation shards by whole chunks and the
+    colour loop by whole calc_normal calls (`pifuhd_amd.dist`), every rank returns the identical mesh and
+    rank 0 writes the files."""
+    from . import dist as pdist
     dev = net.device
+    rank, ws = pdist.world() if sharded else (0, 1)
 
     def mark():
         if timings is not None:
@@ -56,30 +75,37 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         pass
     b_min = data['b_min']
     b_max = data['b_max']
-    _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
+    if rank == 0:
+        _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
     t2 = mark()
 
     # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
     # like the reference (reconstruction.py:56)
     verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, b_min, b_max, thresh, use_octree=use_octree,
-                                        num_samples=5000)
+                                        num_samples=5000, sharded=sharded)
     t3 = mark()
     verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
 
-    color = np.zeros(verts.shape)
-    interval = 50000
-    for i in range(len(color) // interval + 1):
-        left = i * interval
-        if i == len(color) // interval:
-            right = -1                      # reference quirk: the last vertex keeps colour 0
-        else:
-            right = (i + 1) * interval
+    spans = _normal_spans(len(verts))
+    if any(r == l for (l, r) in spans):
+        # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+        raise RuntimeError('calc_normal on an empty vertex slice')
+
+    def normals_of(left, right):
         net.calc_normal(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor)
-        nml = net.nmls.detach().cpu().numpy()[0] * 0.5 + 0.5
-        color[left:right] = nml.T
+        return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
+
+    color32 = pdist.sharded_calls(spans, normals_of, 3, dev) if ws > 1 else None
+    if color32 is None:
+        color32 = torch.zeros(spans[-1][1], 3, device=dev, dtype=torch.float32)
+        for (l, r) in spans:
+            color32[l:r] = normals_of(l, r)
+    color = np.zeros(verts.shape)
+    color[:color32.shape[0]] = color32.cpu().numpy()
     t4 = mark()
 
-    save_obj_mesh_with_color(save_path, verts, faces, color)
+    if rank == 0:
+        save_obj_mesh_with_color(save_path, verts, faces, color)
     t5 = time.perf_counter()
     if timings is not None:
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,

@@ -94,3 +94,61 @@ def test_sharded_eval_gloo_world2_matches_single_process():
     with torch.no_grad():
         whole = nets.query(pts, calib_tensor())[0, 0].numpy()
     assert np.abs(whole - want).max() > 1e-4
+
+
+def test_normal_spans_follow_reference_colour_loop():
+    """`reconstruction.py:58-70`: 50 000-vertex slices, the last one ends at -1."""
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.reconstruction import _normal_spans
+    for v in (1, 2, 49999, 50000, 50001, 50002, 120000, 249422):
+        want = []
+        idx = np.arange(v)
+        for i in range(v // 50000 + 1):
+            left = i * 50000
+            right = -1 if i == v // 50000 else (i + 1) * 50000
+            sl = idx[left:right]
+            want.append((left, left + len(sl)))
+        assert _normal_spans(v) == want
+    assert _normal_spans(100000)[-1] == (100000, 100000)        # empty slice: the reference raises there (C-6)
+
+
+def _calls_worker(rank, ws, port, spans, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.dist import sharded_calls
+    seen = []
+
+    def call_fn(l, r):
+        seen.append((l, r))
+        rows = torch.arange(l, r, dtype=torch.float32)
+        return torch.stack([rows, rows * 2 + 1, -rows], 1)
+    out = sharded_calls(spans, call_fn, 3, torch.device('cpu'))
+    q.put((rank, seen, out.numpy() if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('ws', [2, 3])
+def test_sharded_calls_gloo(ws):
+    """Whole calc_normal calls are distributed; every call runs exactly once; one all-gather rebuilds all rows."""
+    spans = [(0, 7), (7, 14), (14, 21), (21, 28), (28, 30)]          # last call ragged, rows 30.. never visited
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calls_worker, args=(r, ws, port, spans, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(ws)]
+    for p in procs:
+        p.join(timeout=100)
+        assert p.exitcode == 0
+    seen = sorted(s for (_, ss, _) in res for s in ss)
+    assert seen == spans
+    out = [o for (r, _, o) in res if r == 0][0]
+    rows = np.arange(30, dtype=np.float32)
+    assert np.array_equal(out, np.stack([rows, rows * 2 + 1, -rows], 1))
