@@ -80,7 +80,14 @@ struct GemmArgs {
         int pad;
     } steps[40];
     int nsteps;
+    int dbg;   // EXPERIMENTS builds: bit0 skip Y stores, bit1 skip statistics, bit2 skip column init, bit3 skip MFMAs
 };
+
+#ifdef PIFU_GEMM_EXPERIMENTS
+#define PIFU_DBG(a_) ((a_).dbg)
+#else
+#define PIFU_DBG(a_) 0
+#endif
 
 __device__ __forceinline__ int chunk_len(const ChunkGeom &g, int c) { return c == g.nchunks - 1 ? g.last_len : g.chunk; }
 
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
     }
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    if (a.colQ) {   // column sharing: start from the per-column product (gathered while the first tile loads are in flight)
+    if (a.colQ && !(PIFU_DBG(a) & 4)) {   // column sharing: start from the per-column product (gathered while the first tile loads are in flight)
         const int hh = lane >> 5, jj = lane & 31;
         const int c0 = col0 + wn * 64 + jj, c1 = c0 + 32;
         const float wz0 = a.colwz ? a.colwz[c0] : 0.f, wz1 = a.colwz ? a.colwz[c1] : 0.f;
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
             }
         } else if (SCHED == 4 || SCHED == 5) {     // MFMA phase at raised priority
             __builtin_amdgcn_s_setprio(3);
+            if (!(PIFU_DBG(a) & 8))
 #pragma unroll
             for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
             __builtin_amdgcn_s_setprio(0);
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = acc[r] + bias;
-                a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
-                if (row < nvalid) { s += v; q = fmaf(v, v, q); }
+                if (!(PIFU_DBG(a) & 1)) a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
+                if (row < nvalid && !(PIFU_DBG(a) & 2)) { s += v; q = fmaf(v, v, q); }
             }
         }
         if (a.partial) {
@@ -1083,6 +1091,28 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
 
 static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st);
 
+// exact-fp32 GEMM dispatch (EXPERIMENTS builds: PIFU_GEMM_VARIANT=13 selects the rejected 256-row tile kernel when a
+// 256-row tile cannot straddle a chunk; PIFU_GEMM_DBG ablates parts of the kernel for timing studies)
+static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
+{
+#ifdef PIFU_GEMM_EXPERIMENTS
+    if (ctx->gemm_variant == 13 && a.ntm % 2 == 0 && a.g.tpc % 2 == 0) {
+        const int ntm2 = a.ntm / 2;
+        if (a.ntn % 2 == 0)
+            hipLaunchKernelGGL(k_mlp_gemm_big<4>, dim3((unsigned)round_up(ntm2, 8) * (a.ntn / 2)), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_mlp_gemm_big<2>, dim3((unsigned)round_up(ntm2, 8) * a.ntn), dim3(512), 0, st, a);
+        return;
+    }
+    GemmArgs b = a;
+    if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
+    hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+#else
+    (void)ctx;
+    hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);   // MFMA phase at s_setprio 3
+#endif
+}
+
 static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g, int64_t rows, const uint8_t *mask,
                         int mask_bit, float *pred_out, int upto_layer /* exclusive; nlayers for all */, hipStream_t st)
 {
@@ -1175,11 +1205,11 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             case 10: if (table_ok) { hipLaunchKernelGGL(k_mlp_gemm_v2, dim3(nblocks), dim3(256), 0, st, a); break; }
                      hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
             case 11: hipLaunchKernelGGL((k_mlp_gemm<32, 5>), dim3(std::min(nblocks, 2 * ctx->num_cus)), dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
+            default: launch_fp32_gemm(ctx, a, st); break;
             }
 #else
-            (void)table_ok;
-            hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a);   // MFMA phase at s_setprio 3
+            (void)table_ok; (void)nblocks;
+            launch_fp32_gemm(ctx, a, st);
 #endif
             }
             if (ctx->prof_on) {
@@ -1359,7 +1389,7 @@ static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
     hipEvent_t e1;
     int rc = prof_begin(ctx, st, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a);
+    launch_fp32_gemm(ctx, a, st);
     if (e1) {
         PIFU_HIP(hipEventRecord(e1, st));
         ctx->prof_flops += flops;

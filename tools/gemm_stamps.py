@@ -55,3 +55,30 @@ for k, iv in per.items():
     tot = sum(w.values()); conc.append({c: round(v / tot, 3) for c, v in sorted(w.items())})
 print('time share by number of resident blocks, first 5 CUs:', conc[:5])
 dur = (cen[:, :, 1].max(1) - cen[:, 0, 0]); print('block duration cyc: median', int(np.median(dur)), 'min', int(dur.min()), 'max', int(dur.max()))
+
+# ---- per-CU timelines: gaps between consecutive blocks of a slot, phase offset of the two resident blocks
+gaps = []; phases = []; starts0 = []
+for k, iv in per.items():
+    iv = sorted(iv)
+    # assign to 2 slots greedily
+    slots = [[], []]
+    for s, e in iv:
+        for sl in slots:
+            if not sl or sl[-1][1] <= s:
+                sl.append((s, e)); break
+    for sl in slots:
+        for (s0, e0), (s1, e1) in zip(sl[:-1], sl[1:]):
+            gaps.append(s1 - e0)
+    if slots[0] and slots[1]:
+        for (s0, e0) in slots[0][1:4]:
+            # nearest block of the other slot that overlaps
+            for (s1, e1) in slots[1]:
+                if s1 < e0 and e1 > s0:
+                    phases.append(((s1 - s0) % (e0 - s0)) / (e0 - s0)); break
+gaps = np.array(gaps); phases = np.array(phases)
+print('slot gap (end of a block -> begin of the next on the same slot) cyc: median', int(np.median(gaps)), 'p10', int(np.percentile(gaps, 10)), 'p90', int(np.percentile(gaps, 90)))
+print('phase offset of the co-resident block (fraction of a tile): hist', np.histogram(phases, bins=10, range=(0, 1))[0].tolist())
+t0 = cen[:, 0, 0].min()
+print('first 16 block begins (cyc since first):', sorted((cen[:, 0, 0] - t0).tolist())[:16])
+print('begin of blocks 500..530:', (cen[500:530, 0, 0] - t0).tolist())
+print('kernel span cyc', int(cen[:, :, 1].max() - t0), 'sum of block durations / (span * 512)', float(dur.sum() / ((cen[:, :, 1].max() - t0) * 512.0)))
