@@ -162,6 +162,19 @@ int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream
 int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
                      float *normals, pifu_stream stream);
 
+/* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
+ * reconstruction.py:112-115): bilinear grid_sample, align_corners=True, zero padding.
+ * feat: device fp32 NCHW [C][H][W] (batch 1); uv: device fp32 [2][n]; out: device fp32 [C][n]. */
+int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const float *uv, int64_t n,
+               float *out, pifu_stream stream);
+
+/* ---- image half of readDataset.get_item (readData.py:15-29 addrect, :83-86 cv2.resize, :96-104 ToTensor+Normalize):
+ * crop rect = (x, y, w, h) of a BGR uint8 image with a zero border where it leaves the image, resize to size x size
+ * with cv2.resize's INTER_LINEAR 8-bit fixed-point arithmetic (INTER_AREA 2x2 mean when the crop is exactly
+ * 2*size), BGR -> RGB, v/255, (t-0.5)/0.5.  bgr: device u8 [H][W][3]; out: device fp32 [3][size][size]. */
+int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
+                          float *out, pifu_stream stream);
+
 /* ---- measurement hook (bench.py / profiles): HIP-event timing of every k_mlp_gemm launch on its own stream --
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms),
  * number of launches and the ALGORITHMIC FLOPs of those launches (2 * valid points * Cout * Cin). */

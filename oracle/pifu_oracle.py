@@ -477,3 +477,78 @@ def analytic_field(points: np.ndarray) -> np.ndarray:
     """Network-independent test field of SURVEY 8d: sigmoid((0.35 - |(0.8x,0.45y,1.6z)|) / 0.01)."""
     r = np.sqrt((0.8 * points[0]) ** 2 + (0.45 * points[1]) ** 2 + (1.6 * points[2]) ** 2)
     return (1.0 / (1.0 + np.exp(-(0.35 - r) / 0.01))).astype(np.float32).astype(np.float64)
+
+
+# =============================================================================== f1: input pipeline (readData.py)
+# PARITY UNPINNED for the cv2 part: OpenCV is a third-party dependency of the reference (unpinned version, not
+# installed in this image, and its IPP-enabled wheels do not even agree with its own C++ path to the last bit).
+# What is restated is the published C++ algorithm of cv::resize for CV_8UC3 / INTER_LINEAR (imgproc/resize.cpp:
+# 11-bit fixed-point coefficients, HResizeLinear + VResizeLinear<uchar>, INTER_AREA fast path at exact 2x);
+# `addrect`, the calibration matrices and ToTensor/Normalize follow readData.py line by line.
+def addrect(img: np.ndarray, rect):
+    """`addrect` (`readData.py:15-29`): crop rect = (x, y, w, h) with a zero border where it leaves the image."""
+    x, y, w, h = [int(v) for v in rect]
+    H, W = img.shape[:2]
+    left = abs(x) if x < 0 else 0
+    top = abs(y) if y < 0 else 0
+    right = abs(W - (x + w)) if x + w >= W else 0
+    bottom = abs(H - (y + h)) if y + h >= H else 0
+    padded = np.zeros((H + top + bottom, W + left + right, img.shape[2]), img.dtype)
+    padded[top:top + H, left:left + W] = img
+    x, y = x + left, y + top
+    return padded[y:y + h, x:x + w, :]
+
+
+def _lin_coords(dsize, ssize, clamp_weights):
+    scale = 1.0 / (float(dsize) / float(ssize))                  # cv::resize: scale = 1 / inv_scale
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_weights:                                            # x axis: fx = 0 at the borders (resize.cpp xofs/alpha loop)
+        lo = s < 0
+        f[lo] = 0; s[lo] = 0
+        hi = s >= ssize - 1
+        f[hi] = 0; s[hi] = ssize - 1
+        s0, s1 = s, np.minimum(s + 1, ssize - 1)
+    else:                                                        # y axis: rows are clamped, weights kept
+        s0, s1 = np.clip(s, 0, ssize - 1), np.clip(s + 1, 0, ssize - 1)
+    w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)      # saturate_cast<short>: round half to even
+    w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s0, s1, w0, w1
+
+
+def cv2_resize_linear_u8(img: np.ndarray, dsize: int) -> np.ndarray:
+    """cv2.resize(img, (dsize, dsize)) for uint8 HxWxC, default INTER_LINEAR (C++ path, see the header above)."""
+    H, W = img.shape[:2]
+    src = img.astype(np.int64)
+    if W == 2 * dsize and H == 2 * dsize:                        # INTER_LINEAR -> INTER_AREA fast path at exactly 2x
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x0, x1, a0, a1 = _lin_coords(dsize, W, True)
+    y0, y1, b0, b1 = _lin_coords(dsize, H, False)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]          # HResizeLinear (int)
+    S0, S1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (S0 >> 4)) >> 16) + ((b1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def preprocess_image(bgr: np.ndarray, rect, size: int) -> np.ndarray:
+    """crop + resize + BGR->RGB + ToTensor + Normalize(0.5, 0.5) (`readData.py:68,83-84,96-103`) -> float32 [3,size,size]."""
+    im = cv2_resize_linear_u8(addrect(bgr, rect), size)
+    rgb = im[:, :, ::-1].astype(np.float32) / np.float32(255)
+    return np.ascontiguousarray(((rgb - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1))
+
+
+def calib_matrices(rect, w: int, h: int):
+    """`calib` and `calib_world` of `readData.py:71-95` (float32 4x4 each)."""
+    trans_mat = np.identity(4)
+    scale_im2ndc = 1.0 / float(w // 2)
+    scale = w / rect[2]
+    trans_mat *= scale
+    trans_mat[3, 3] = 1.0
+    trans_mat[0, 3] = -scale * (rect[0] + rect[2] // 2 - w // 2) * scale_im2ndc
+    trans_mat[1, 3] = scale * (rect[1] + rect[3] // 2 - h // 2) * scale_im2ndc
+    intrinsic = np.matmul(trans_mat, np.identity(4))
+    proj = np.identity(4)
+    proj[1, 1] = -1
+    return proj.astype(np.float32), intrinsic.astype(np.float32)

@@ -56,6 +56,8 @@ SIGNATURES = {
     'pifu_mc_count': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _d, C.POINTER(_i64), C.POINTER(_i64), _p]),
     'pifu_mc_emit': (_i32, [_p, _p, _p, _p]),
     'pifu_calc_normal': (_i32, [_p, _p, _i64, _p, _f, _p, _p]),
+    'pifu_index': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
+    'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
     'pifu_profile_enable': (_i32, [_p, _i32]),
     'pifu_profile_read': (_i32, [_p, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
     'pifu_write_obj': (_i32, [C.c_char_p, _p, _p, _i64, _p, _i64]),

@@ -101,8 +101,33 @@ def _push_encoder_params(ctx, sd, prefix):
         _lib.call('pifu_enc_set_param', ctx.h, (prefix + key).encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
 
 
+def orthogonal(points, calib, transform=None):
+    """`orthogonal` (`BasePIFuNet.py:25-43`): xyz = R p + t for points [B,3,N], calib [B,4,4] (device tensors)."""
+    if transform is not None:
+        raise NotImplementedError('screen-space `transforms` are never used on the reconstruction path')
+    rot = calib[:, :3, :3]
+    trans = calib[:, :3, 3:4]
+    return torch.baddbmm(trans, rot, points)
+
+
+def index(feat, uv, ctx=None):
+    """`index` (`BasePIFuNet.py:11-23`): feat [1,C,H,W], uv [1,2,N] -> [1,C,N] through `pifu_index` (HIP)."""
+    if feat.dim() != 4 or feat.shape[0] != 1 or uv.dim() != 3 or uv.shape[0] != 1 or uv.shape[1] != 2:
+        raise NotImplementedError('index(): batch size 1, feat [1,C,H,W], uv [1,2,N]')
+    if not feat.is_cuda:
+        raise _lib.PifuError(_lib.ERR_INVALID, 'the HIP path needs device tensors (no CPU fallback)')
+    ctx = ctx or _Ctx(feat.device)
+    f = feat[0].float().contiguous()
+    u = uv[0].to(feat.device, torch.float32).contiguous()
+    out = torch.empty(f.shape[0], u.shape[1], device=feat.device, dtype=torch.float32)
+    _lib.call('pifu_index', ctx.h, _ptr(f), f.shape[0], f.shape[1], f.shape[2], _ptr(u), u.shape[1], _ptr(out),
+              _stream_ptr(ctx.device))
+    return out[None]
+
+
 class BasePIFuNet:
     """API shell (`BasePIFuNet.py:67-148`)."""
+    projection = staticmethod(orthogonal)
 
     def __init__(self, projection_mode='orthogonal'):
         if projection_mode not in ('orthogonal', 'otthogonal'):      # 'otthogonal': PIFuMRNet.py:22 default typo

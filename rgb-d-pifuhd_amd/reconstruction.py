@@ -13,7 +13,10 @@ import time
 import numpy as np
 import torch
 
+from numpy.linalg import inv
+
 from .mesh_util import reconstruction, save_obj_mesh_with_color
+from .nets import index
 
 
 def _save_debug_png(path, image_tensor_global):
@@ -111,3 +114,43 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,
                        total_s=t5 - t0, n_verts=len(verts), n_faces=len(faces))
     return verts, faces, color
+
+
+def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False):
+    """`gen_mesh_imgColor` (`reconstruction.py:77-125`): same mesh, 100 000-point query chunks, vertex colours sampled
+    from the input image at the projected vertices, vertices mapped back through `calib_world`.  Like the reference,
+    everything after the filters runs inside a try block that prints 'error' and the exception."""
+    dev = net.device
+    image_tensor_global = data['img_512'].to(device=dev)
+    image_tensor = data['img'].to(device=dev)
+    calib_tensor = data['calib'].to(device=dev)
+
+    net.filter_global(image_tensor_global)
+    net.filter_local(image_tensor[:, None])
+    try:
+        if net.netG.netF is not None:
+            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlF], 0)
+        if net.netG.netB is not None:
+            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlB], 0)
+    except Exception:
+        pass
+    b_min = data['b_min']
+    b_max = data['b_max']
+    try:
+        _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
+        verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, b_min, b_max, thresh, use_octree=use_octree,
+                                            num_samples=100000)
+        verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
+        xyz_tensor = net.projection(verts_tensor, calib_tensor[:1])
+        uv = xyz_tensor[:, :2, :]
+        color = index(image_tensor[:1], uv, net._ctx).detach().cpu().numpy()[0].T
+        color = color * 0.5 + 0.5
+        if 'calib_world' in data:
+            calib_world = data['calib_world'].numpy()[0]
+            verts = np.matmul(np.concatenate([verts, np.ones_like(verts[:, :1])], 1), inv(calib_world).T)[:, :3]
+        save_obj_mesh_with_color(save_path, verts, faces, color)
+        return verts, faces, color
+    except Exception as e:
+        print('error')
+        print(e)
+        return None

@@ -103,3 +103,39 @@ def test_sharded_entry_points_single_rank():
     dense = pdist.eval_lattice_sharded(netMR, calib, (16, 32, 24), 5000)
     d2, _ = mesh_util.eval_grid_device(netMR, calib, 32, 5000, use_octree=False)
     assert dense.shape[0] == 16 * 32 * 24 and torch.isfinite(dense).all() and d2.shape == (32, 32, 32)
+
+
+def test_gen_mesh_imgcolor(tmp_path, capsys):
+    """`gen_mesh_imgColor` (`reconstruction.py:77-125`): 100 000-point chunks, colours = index(image, projected verts),
+    vertices through inv(calib_world); failures are printed, not raised."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util, nets, reconstruction, synth
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    world = torch.tensor([[[1.7, 0, 0, 0.2], [0, 1.7, 0, -0.1], [0, 0, 1.7, 0], [0, 0, 0, 1]]])
+    data = {'name': 't', 'img': synth.synthetic_image(128, 3, seed=3), 'img_512': synth.synthetic_image(64, 3, seed=2),
+            'calib': calib_tensor(), 'calib_world': world, 'b_min': [-1, -1, -1], 'b_max': [1, 1, 1]}
+    netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
+    path = str(tmp_path / 'mesh.obj')
+    out = reconstruction.gen_mesh_imgColor(64, netMR, 'cuda', data, path)
+    assert out is not None and os.path.exists(path) and os.path.exists(path[:-4] + '.png')
+    verts, faces, color = out
+    # the mesh before the world transform = reconstruction() with 100 000-point chunks
+    v0, f0, _, _ = mesh_util.reconstruction(netMR, 'cuda', data['calib'], 64, None, None, 0.5, use_octree=True,
+                                            num_samples=100000)
+    assert np.array_equal(f0, faces)
+    want_v = np.matmul(np.concatenate([v0, np.ones_like(v0[:, :1])], 1), np.linalg.inv(world[0].numpy()).T)[:, :3]
+    assert np.array_equal(want_v, verts)
+    xyz = O.orthogonal(torch.from_numpy(v0.T).float()[None], data['calib'])
+    want_c = O.index(data['img'][:1], xyz[:, :2])[0].numpy().T * 0.5 + 0.5
+    assert np.abs(color - want_c).max() < 1e-5
+    assert open(path).read() == O.obj_text(verts, faces, color)
+    # chunk size is part of the numerical contract: 5 000-point chunks give a different field
+    v5, f5, _, _ = mesh_util.reconstruction(netMR, 'cuda', data['calib'], 64, None, None, 0.5, use_octree=True, num_samples=5000)
+    assert v5.shape != v0.shape or not np.array_equal(v5, v0)
+    # errors are swallowed and printed, like the reference's try/except
+    capsys.readouterr()
+    assert reconstruction.gen_mesh_imgColor(48, netMR, 'cuda', data, path) is None
+    assert 'error' in capsys.readouterr().out
