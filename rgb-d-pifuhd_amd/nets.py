@@ -196,6 +196,31 @@ class PIFuNetwNML(BasePIFuNet):
                     for k in spec if k in state_dict}
         self._push_weights()
 
+    def state_dict(self):
+        """Flat dict keyed like the reference module's `state_dict()` (no 'netG.' prefix)."""
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'no weights loaded')
+        return dict(self._sd)
+
+    def loadFromPIFu(self, net):
+        """`PIFuNetwNML.loadFromPIFu` (`PIFuNetwNML.py:144-179`): copy every `image_filter.*` / `mlp.*` tensor of `net`
+        whose key and shape match this net's; prints the top-level names left uninitialised, like the reference.
+        (The reference starts from its random initialisation; here this net must already hold weights.)"""
+        mine, theirs = self.state_dict(), net.state_dict()
+        for part, label in (('image_filter.', 'not initialized'), ('mlp.', 'mlp not initialized')):
+            not_init = set()
+            for k, v in mine.items():
+                if not k.startswith(part):
+                    continue
+                t = theirs.get(k)
+                if t is not None and tuple(t.shape) == tuple(v.shape):
+                    mine[k] = t.detach().to(self.device, v.dtype)
+                else:
+                    not_init.add(k[len(part):].split('.')[0])
+            print(label, sorted(not_init))
+        self._sd = mine
+        self._push_weights()
+
     def _push_weights(self):
         o = self.opt
         # eval mode on the reconstruction path (reconstruction.py:288-289): running stats for 'batch'
@@ -314,6 +339,14 @@ class PIFuMRNet(BasePIFuNet):
         self._sd = {k: state_dict[k].detach().to(self.device, torch.float32)
                     if state_dict[k].dtype.is_floating_point else state_dict[k] for k in own if k in state_dict}
         self._push_weights()
+
+    def state_dict(self):
+        """Flat dict with the reference's key scheme: own tensors + the coarse net's under 'netG.'."""
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'no weights loaded')
+        out = dict(self._sd)
+        out.update({'netG.' + k: v for k, v in self.netG.state_dict().items()})
+        return out
 
     def _push_weights(self):
         o = self.opt

@@ -8,6 +8,7 @@ at -1; a vertex count that is a multiple of 50 000 raises like the reference doe
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -154,3 +155,92 @@ def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=Tr
         print('error')
         print(e)
         return None
+
+
+# ------------------------------------------------------------------------------------------------
+# Checkpoints and the recon() driver (reconstruction.py:232-321)
+# ------------------------------------------------------------------------------------------------
+def load_checkpoint(path, map_location='cpu'):
+    """The reference's checkpoint is `{'opt': Namespace, 'opt_netG': Namespace, 'model_state_dict': dict}` written with
+    torch.save (`train.py`); `recon` reads it with a plain `torch.load` (`reconstruction.py:253-256`).  Loaded with the
+    weights-only unpickler plus `argparse.Namespace`, so a checkpoint cannot execute code."""
+    import argparse
+    import types
+    with torch.serialization.safe_globals([argparse.Namespace, types.SimpleNamespace]):
+        return torch.load(path, map_location=map_location, weights_only=True)
+
+
+def save_checkpoint(path, opt, opt_netG, netMR):
+    """Counterpart of the reference's `torch.save` of a training state (same three keys)."""
+    import argparse
+
+    def ns(o):
+        return o if isinstance(o, argparse.Namespace) else argparse.Namespace(**vars(o))
+    torch.save({'opt': ns(opt), 'opt_netG': ns(opt_netG),
+                'model_state_dict': {k: v.detach().cpu() for k, v in netMR.state_dict().items()}}, path)
+
+
+def recon(opt, use_crop=False, use_gpu=True, dataset=None):
+    """`recon` (`reconstruction.py:231-321`): resolve the checkpoint path, overwrite `opt` with the checkpoint's (keeping
+    dataroot / resolution / results_path / loadSize), build both nets, `netG.eval()` only, loop the dataset.
+    `use_gpu=False` raises: this path has no CPU implementation.  `dataset` overrides `readDataset(opt.dataroot, ...)`."""
+    from .nets import PIFuMRNet, PIFuNetwNML
+    from .readData import readDataset
+    if opt.load_netMR_checkpoint_path is not None:
+        state_dict_path = opt.load_netMR_checkpoint_path
+    elif opt.resume_epoch < 0:
+        state_dict_path = '%s/%s_train_latest' % (opt.checkpoints_path, opt.name)
+        opt.resume_epoch = 0
+    else:
+        state_dict_path = '%s/%s_train_epoch_%d' % (opt.checkpoints_path, opt.name, opt.resume_epoch)
+    if not use_gpu:
+        raise NotImplementedError('the HIP path needs a GPU (no CPU fallback)')
+    cuda = torch.device('cuda:%d' % opt.gpu_id)
+    start_id, end_id, use_color = opt.start_id, opt.end_id, opt.use_color
+
+    if state_dict_path is not None and os.path.exists(state_dict_path):
+        print('Resuming from', state_dict_path)
+        state_dict = load_checkpoint(state_dict_path)
+        print('Load {} success!'.format(state_dict_path))
+        print('Warning: opt is overwritten.')
+        dataroot, resolution, results_path, loadSize = opt.dataroot, opt.resolution, opt.results_path, opt.loadSize
+        opt = state_dict['opt']
+        opt.dataroot, opt.resolution, opt.results_path, opt.loadSize = dataroot, resolution, results_path, loadSize
+        print('Options has been updated!')
+    else:
+        raise Exception('Failed loading state dict!', state_dict_path)
+
+    print('Reading test images...')
+    test_dataset = dataset if dataset is not None else readDataset(opt.dataroot, opt.loadSize, use_crop=use_crop, device=cuda)
+    print('Read success!')
+    print('num of test images:', len(test_dataset))
+    projection_mode = test_dataset.projection_mode
+    opt_netG = state_dict['opt_netG']
+    netG = PIFuNetwNML(opt_netG, projection_mode, device=cuda)
+    netMR = PIFuMRNet(opt, netG, projection_mode)
+    netMR.load_state_dict(state_dict['model_state_dict'])
+
+    results_save_path = '{}/{}/recon'.format(opt.results_path, opt.name)
+    os.makedirs(opt.checkpoints_path, exist_ok=True)
+    os.makedirs(opt.results_path, exist_ok=True)
+    os.makedirs(results_save_path, exist_ok=True)
+    start_id = 0 if start_id < 0 else start_id
+    end_id = len(test_dataset) if end_id < 0 else end_id
+    netG.eval()                                       # reconstruction.py:288-289,304: netMR stays in train mode
+    written = []
+    for i in range(start_id, end_id):
+        if i >= len(test_dataset):
+            break
+        test_data = test_dataset[i]
+        result_save_path = results_save_path + '/result_{}_{}.obj'.format(test_data['name'], opt.resolution)
+        print(result_save_path)
+        if use_color == 0:
+            gen_mesh(opt.resolution, netMR, cuda, test_data, result_save_path, components=opt.use_compose)
+        elif use_color == 1:
+            gen_mesh_imgColor(opt.resolution, netMR, cuda, test_data, result_save_path, components=opt.use_compose)
+        elif use_color == 2:
+            raise NotImplementedError('gen_mesh_imgColor_plus (trimesh mesh cleaning + back-side recolouring) is not built')
+        else:
+            raise NameError('unknown downsampling type')      # reconstruction.py:321 (message as in the reference)
+        written.append(result_save_path)
+    return written

@@ -67,3 +67,17 @@ def test_obj_writer_host_only(lib, tmp_path):
     p = tmp_path / 'a.obj'
     mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
     assert p.read_text() == O.obj_text(v, f, c)
+
+
+def test_checkpoint_io_roundtrip(tmp_path):
+    """The reference's checkpoint layout loads through the weights-only unpickler (argparse.Namespace allowed)."""
+    import argparse
+    import torch
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import reconstruction
+    p = str(tmp_path / 'ck')
+    torch.save({'opt': argparse.Namespace(name='x', mlp_dim=[272, 512, 1]), 'opt_netG': argparse.Namespace(loadSize=512),
+                'model_state_dict': {'mlp.filters.0.weight': torch.arange(6.).view(1, 6, 1)}}, p)
+    ck = reconstruction.load_checkpoint(p)
+    assert ck['opt'].name == 'x' and ck['opt_netG'].loadSize == 512
+    assert torch.equal(ck['model_state_dict']['mlp.filters.0.weight'], torch.arange(6.).view(1, 6, 1))

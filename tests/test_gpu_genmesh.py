@@ -139,3 +139,51 @@ def test_gen_mesh_imgcolor(tmp_path, capsys):
     capsys.readouterr()
     assert reconstruction.gen_mesh_imgColor(48, netMR, 'cuda', data, path) is None
     assert 'error' in capsys.readouterr().out
+
+
+def test_recon_driver_checkpoint_roundtrip(tmp_path, capsys):
+    """`recon` (`reconstruction.py:231-321`): checkpoint {'opt','opt_netG','model_state_dict'} -> nets -> dataset loop."""
+    import argparse
+    from PIL import Image
+    from pifuhd_amd import nets, reconstruction, synth
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    # a subject on disk: 128 px PNG + rect covering it
+    img = ((synth.synthetic_image(128, 3, seed=3)[0].permute(1, 2, 0).numpy() * 0.5 + 0.5) * 255).round().astype(np.uint8)
+    root = tmp_path / 'data'; os.makedirs(root)
+    Image.fromarray(img).save(root / 'subj.png')
+    (root / 'subj_rect.txt').write_text('0 0 128 128\n')
+    from pifuhd_amd.readData import readDataset
+    ds = readDataset(str(root), loadsize=128)
+    data = ds[0]
+    netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
+    opt_ck = argparse.Namespace(**vars(of)); opt_ck.name = 'unit'; opt_ck.checkpoints_path = str(tmp_path / 'ck')
+    opt_ck.use_compose = False
+    os.makedirs(opt_ck.checkpoints_path)
+    ck = os.path.join(opt_ck.checkpoints_path, 'unit_train_latest')
+    reconstruction.save_checkpoint(ck, opt_ck, oc, netMR)
+    loaded = reconstruction.load_checkpoint(ck)
+    assert set(loaded) == {'opt', 'opt_netG', 'model_state_dict'} and loaded['opt'].name == 'unit'
+    assert set(loaded['model_state_dict']) == set(netMR.state_dict())
+    want_v, want_f, want_c = reconstruction.gen_mesh(64, netMR, 'cuda', data, str(tmp_path / 'direct.obj'))
+    opt = argparse.Namespace(load_netMR_checkpoint_path=None, resume_epoch=-1, checkpoints_path=opt_ck.checkpoints_path,
+                             name='unit', gpu_id=0, start_id=-1, end_id=-1, use_color=0, dataroot=str(root), resolution=64,
+                             results_path=str(tmp_path / 'results'), loadSize=128)
+    written = reconstruction.recon(opt, use_crop=False, use_gpu=True)
+    assert written == [str(tmp_path / 'results') + '/unit/recon/result_subj_64.obj']
+    assert open(written[0]).read() == open(tmp_path / 'direct.obj').read()
+    with pytest.raises(Exception, match='Failed loading state dict'):
+        opt.name = 'nope'; opt.resume_epoch = 3
+        reconstruction.recon(opt)
+    # loadFromPIFu: same architecture => everything copied; a wider MLP keeps its own mlp tensors
+    sd2, _, _ = golden_nets()
+    other = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda'); other.eval()
+    other.load_state_dict({k: v + 1.0 if v.dtype.is_floating_point else v for k, v in sd2.items()}, _prefix='netG.')
+    capsys.readouterr()
+    other.loadFromPIFu(netG)
+    out = capsys.readouterr().out
+    assert 'not initialized []' in out and 'mlp not initialized []' in out
+    assert all(torch.equal(other.state_dict()[k].cpu(), netG.state_dict()[k].cpu()) for k in netG.state_dict()
+               if k.startswith(('image_filter.', 'mlp.')))
