@@ -308,27 +308,34 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
         unsigned long long *o = a.stamps + 64 * 40 * 4 + ((size_t)blockIdx.x * 4 + wave) * 4;
         o[0] = t_begin; o[1] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_getreg(63492); o[3] = __builtin_amdgcn_s_getreg(63508);
     }
-    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
+    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows.  Addresses are a uniform
+    // (scalar) tile base + a per-lane 32-bit byte offset, so the 64 stores per lane need no vector address arithmetic
+    // (every VALU instruction here is time the partner wave's fp32 MFMA stream does not get).
     const int h = lane >> 5, j = lane & 31;
     const int local0 = (tile_m % a.g.tpc) * BM;
     int nvalid = chunk_len(a.g, chunk_id) - local0;
     nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
     float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
+    char *ytile = reinterpret_cast<char *>(a.Y + row0 * (size_t)a.ldy + col0);                     // uniform
+    const unsigned ldy4 = (unsigned)a.ldy * 4u;
+    const unsigned voff = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;       // per lane
+    const bool full = nvalid >= BM;
 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int col = col0 + wn * 64 + nt * 32 + j;
-        const float bias = a.bias[col];
+        const float bias = a.bias[col0 + wn * 64 + nt * 32 + j];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int rr = mt * 32 + (r & 3) + 8 * (r >> 2);                                  // uniform part of the row
                 const float v = acc[r] + bias;
-                if (!(PIFU_DBG(a) & 1)) a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
-                if (row < nvalid && !(PIFU_DBG(a) & 2)) { s += v; q = fmaf(v, v, q); }
+                if (!(PIFU_DBG(a) & 1))
+                    *reinterpret_cast<float *>(ytile + ((size_t)rr * ldy4 + nt * 128) + voff) = v;
+                if (full) { s += v; q = fmaf(v, v, q); }
+                else if (wm * 64 + rr + 4 * h < nvalid) { s += v; q = fmaf(v, v, q); }
             }
         }
         if (a.partial) {
@@ -348,6 +355,208 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
     }
     if (SCHED == 5) __syncthreads();     // the next tile's prologue overwrites the LDS scratch used above
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mlp_gemm_buf: k_mlp_gemm<32, 4> with buffer addressing.  On gfx950 the fp32 MFMA shares the vector ALUs, so every
+// VALU instruction of the staging path, the column-init gather and the epilogue is matrix time lost.  All global
+// accesses here are `buffer_load/store ... s[rsrc], soffset offen`: a uniform (SGPR) tile descriptor + a per-lane 32-bit
+// byte offset + a scalar offset, so no 64-bit vector address arithmetic is left; the norm + LeakyReLU transform runs on
+// packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).  Same tiles, same LDS layout, same MFMA and summation order as
+// k_mlp_gemm<32, 4>: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
+{
+    constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // [buf][A|B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q_tile = blockIdx.x;
+    const int xcd = q_tile & 7, slot = q_tile >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM;
+    const int col0 = tile_n * BN;
+
+    const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
+    const unsigned kb = kq * 16;
+    const int b1 = a.seg[0].width;
+    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
+    const int nsteps = a.ldw / TBK;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
+    const unsigned voW = (unsigned)sr * ldw4 + kb;
+
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
+    float rslope = 1.f;
+
+#define BUF_GLOAD(step_)                                                                                   \
+    {                                                                                                      \
+        const int kk = (step_) * TBK;                                                                      \
+        const int sg = (kk >= b1) + (kk >= b2);                                                            \
+        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
+        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
+        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
+        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
+        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
+        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
+        rslope = md == 0 ? 1.f : 0.01f;                                                                    \
+        const unsigned ks4 = (unsigned)(kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2))) * 4u;                    \
+        const unsigned ld4 = (unsigned)ld * 4u;                                                            \
+        const __amdgpu_buffer_rsrc_t rA = buf_rsrc(ptr + row0 * (size_t)ld);                               \
+        const unsigned voA = (unsigned)sr * ld4 + kb;                                                      \
+        ra0 = buf_load4(rA, voA, ks4);                                                                     \
+        ra1 = buf_load4(rA, voA, ks4 + 32u * ld4);                                                         \
+        ra2 = buf_load4(rA, voA, ks4 + 64u * ld4);                                                         \
+        ra3 = buf_load4(rA, voA, ks4 + 96u * ld4);                                                         \
+        rsc = buf_load4(buf_rsrc(sc + (size_t)chunk_id * sld), kb, ks4);                                   \
+        rsh = buf_load4(buf_rsrc(sh + (size_t)chunk_id * sld), kb, ks4);                                   \
+        const unsigned kw4 = (unsigned)kk * 4u;                                                            \
+        rw0 = buf_load4(rW, voW, kw4);                                                                     \
+        rw1 = buf_load4(rW, voW, kw4 + 32u * ldw4);                                                        \
+        rw2 = buf_load4(rW, voW, kw4 + 64u * ldw4);                                                        \
+        rw3 = buf_load4(rW, voW, kw4 + 96u * ldw4);                                                        \
+    }
+    // norm affine + LeakyReLU on packed pairs: t = v * sc + sh;  v = max(t, slope * t)
+#define BUF_XF(va_)                                                                                        \
+    {                                                                                                      \
+        f32x2 lo_ = {va_.x, va_.y}, hi_ = {va_.z, va_.w};                                                  \
+        const f32x2 sl_ = {rsc.x, rsc.y}, sh_ = {rsc.z, rsc.w}, bl_ = {rsh.x, rsh.y}, bh_ = {rsh.z, rsh.w}; \
+        const f32x2 k_ = {rslope, rslope};                                                                 \
+        lo_ = __builtin_elementwise_fma(lo_, sl_, bl_);                                                    \
+        hi_ = __builtin_elementwise_fma(hi_, sh_, bh_);                                                    \
+        const f32x2 ml_ = lo_ * k_, mh_ = hi_ * k_;                                                        \
+        va_.x = fmaxf(lo_.x, ml_.x); va_.y = fmaxf(lo_.y, ml_.y);                                          \
+        va_.z = fmaxf(hi_.x, mh_.x); va_.w = fmaxf(hi_.y, mh_.y);                                          \
+    }
+#define BUF_LSTORE(buf_)                                                                                   \
+    {                                                                                                      \
+        float *la = lds + (buf_) * 2 * TILE + sr * LD + kq * 4;                                            \
+        BUF_XF(ra0) BUF_XF(ra1) BUF_XF(ra2) BUF_XF(ra3)                                                    \
+        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
+        *reinterpret_cast<float4 *>(la + 32 * LD) = ra1;                                                   \
+        *reinterpret_cast<float4 *>(la + 64 * LD) = ra2;                                                   \
+        *reinterpret_cast<float4 *>(la + 96 * LD) = ra3;                                                   \
+        *reinterpret_cast<float4 *>(la + TILE) = rw0;                                                      \
+        *reinterpret_cast<float4 *>(la + TILE + 32 * LD) = rw1;                                            \
+        *reinterpret_cast<float4 *>(la + TILE + 64 * LD) = rw2;                                            \
+        *reinterpret_cast<float4 *>(la + TILE + 96 * LD) = rw3;                                            \
+    }
+
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    BUF_GLOAD(0)
+    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
+        const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
+        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);     // descriptors stay block-uniform (SGPRs)
+        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
+        const float wz0 = a.colwz ? a.colwz[col0 + wn * 64 + j] : 0.f, wz1 = a.colwz ? a.colwz[col0 + wn * 64 + 32 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+            const unsigned ciA = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so, 0);
+            const unsigned ciB = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so + 128u, 0);
+            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
+            const unsigned qA = ciA * ldq4 + (unsigned)(wn * 64 + j) * 4u, qB = ciB * ldq4 + (unsigned)(wn * 64 + j) * 4u;
+            acc00[r] = fmaf(wz0, zA, buf_load1(rQ, qA, 0));
+            acc01[r] = fmaf(wz1, zA, buf_load1(rQ, qA, 128));
+            acc10[r] = fmaf(wz0, zB, buf_load1(rQ, qB, 0));
+            acc11[r] = fmaf(wz1, zB, buf_load1(rQ, qB, 128));
+        }
+    }
+    BUF_LSTORE(0)
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) BUF_GLOAD(step + 1)
+        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
+            const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) BUF_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
+    const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
+    const unsigned ldy4 = (unsigned)a.ldy * 4u;
+    const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;
+    const float bias0 = a.bias[col0 + wn * 64 + j], bias1 = a.bias[col0 + wn * 64 + 32 + j];
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#define BUF_EPI(acc_, mt_, nt_, bias_, s_, q_, CHECK_)                                                     \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
+        const int rr = (mt_) * 32 + (r & 3) + 8 * (r >> 2);                                                \
+        const float v = acc_[r] + bias_;                                                                   \
+        buf_store1(v, rY, voY, (unsigned)rr * ldy4 + (nt_) * 128u);                                        \
+        if (!(CHECK_) || wm * 64 + rr + 4 * h < nvalid) { s_ += v; q_ = fmaf(v, v, q_); }                  \
+    }
+    if (nvalid >= BM) {
+        BUF_EPI(acc00, 0, 0, bias0, s0, q0, false) BUF_EPI(acc10, 1, 0, bias0, s0, q0, false)
+        BUF_EPI(acc01, 0, 1, bias1, s1, q1, false) BUF_EPI(acc11, 1, 1, bias1, s1, q1, false)
+    } else {
+        BUF_EPI(acc00, 0, 0, bias0, s0, q0, true) BUF_EPI(acc10, 1, 0, bias0, s0, q0, true)
+        BUF_EPI(acc01, 0, 1, bias1, s1, q1, true) BUF_EPI(acc11, 1, 1, bias1, s1, q1, true)
+    }
+    if (a.partial) {
+        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+        s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+        if (lane < 32) {
+            red[(0 * 2 + wm) * BN + wn * 64 + j] = s0;
+            red[(1 * 2 + wm) * BN + wn * 64 + j] = q0;
+            red[(0 * 2 + wm) * BN + wn * 64 + 32 + j] = s1;
+            red[(1 * 2 + wm) * BN + wn * 64 + 32 + j] = q1;
+        }
+        __syncthreads();
+        if (tid < BN)
+            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
+    }
 }
 
 #ifdef PIFU_GEMM_EXPERIMENTS
@@ -1108,8 +1317,10 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
     hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
 #else
-    (void)ctx;
-    hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);   // MFMA phase at s_setprio 3
+    if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
+        hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_mlp_gemm_buf, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 #endif
 }
 

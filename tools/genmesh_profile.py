@@ -1,4 +1,5 @@
 import sys, time, tempfile, os
+RES = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 sys.path.insert(0, '.')
 import numpy as np, torch
 import pifuhd_amd
@@ -13,11 +14,11 @@ with tempfile.TemporaryDirectory() as td:
     recon.gen_mesh(128, netMR, 'cuda', data, os.path.join(td, 'w.obj'))
     for _ in range(2):
         t = {}
-        recon.gen_mesh(512, netMR, 'cuda', data, os.path.join(td, 'm.obj'), timings=t)
+        recon.gen_mesh(RES, netMR, 'cuda', data, os.path.join(td, 'm.obj'), timings=t)
         print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()}, flush=True)
     # finer breakdown of reconstruction()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    sdf, n = mesh_util.eval_grid_device(netMR, data['calib'], 512, 5000, True); torch.cuda.synchronize(); t1 = time.perf_counter()
+    sdf, n = mesh_util.eval_grid_device(netMR, data['calib'], RES, 5000, True); torch.cuda.synchronize(); t1 = time.perf_counter()
     v, f = mesh_util.marching_cubes_device(netMR._ctx, sdf, 0.5); torch.cuda.synchronize(); t2 = time.perf_counter()
     vh = v.cpu().numpy(); fh = f.cpu().numpy(); t3 = time.perf_counter()
-    print('octree eval %.3f s (%d points evaluated = %.1f%% of grid), MC %.3f s, D2H %.3f s' % (t1 - t0, n, 100.0 * n / 512 ** 3, t2 - t1, t3 - t2))
+    print('octree eval %.3f s (%d points evaluated = %.1f%% of grid), MC %.3f s, D2H %.3f s' % (t1 - t0, n, 100.0 * n / RES ** 3, t2 - t1, t3 - t2))
