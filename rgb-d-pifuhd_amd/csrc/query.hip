@@ -1315,7 +1315,13 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     }
     GemmArgs b = a;
     if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
-    hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+    if (ctx->gemm_variant == 6) {
+        b.stamps = (ctx->debug_buf && a.ldw == 1024) ? (unsigned long long *)ctx->debug_buf : nullptr;   // coarse L1 only
+        hipLaunchKernelGGL(k_mlp_gemm_buf2, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+    } else if (ctx->gemm_variant == 4)
+        hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+    else
+        hipLaunchKernelGGL(k_mlp_gemm_buf, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
 #else
     if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);

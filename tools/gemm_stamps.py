@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 sys.path.insert(0, '.')
-os.environ['PIFU_GEMM_VARIANT'] = '9'
+os.environ.setdefault('PIFU_GEMM_VARIANT', '9'); os.environ['PIFU_DEBUG_STAMPS'] = '1'
 import numpy as np, torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, _lib, dist as pdist
@@ -19,7 +19,7 @@ _lib.call('pifu_reserve', netMR._ctx.h, 262144)
 # coarse only up to layer 1 would be ideal; we simply run the coarse-only path: the LAST gemm launch (coarse L3, K=544)
 # overwrites the stamps, so use a 2-layer trick: evaluate coarse only and read stamps of the last GEMM launched.
 for _ in range(2):
-    pdist.eval_lattice_sharded(netG, calib, (64, 64, 64), 5000, _lib.Q_COARSE_ONLY)
+    pdist.eval_lattice_sharded(netG, calib, (51, 50, 100), 5000, _lib.Q_COARSE_ONLY)   # exactly one batch of 51 chunks
 torch.cuda.synchronize()
 raw = np.zeros(64 * 40 * 4 + 16384 * 16, dtype=np.uint64)
 buf = raw[:64 * 40 * 4].reshape(64, 40, 4)

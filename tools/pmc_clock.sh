@@ -1,8 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
 OUT=gpurun_out/prof2
-mkdir -p $OUT
-SMALL="bench.py --steps 1 --warmup 1 --res 128 --features synthetic --no-cpu-baseline --no-genmesh"
+rm -rf $OUT/pmc; mkdir -p $OUT
+SMALL="bench.py --steps 1 --warmup 1 --res 160 --features synthetic --no-split-precision --no-cpu-baseline --no-genmesh"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/pmc -- python $SMALL > $OUT/bench.json 2> $OUT/err.log
 tail -3 $OUT/err.log
 python - <<'PY'
