@@ -41,7 +41,8 @@ def pmc(dirname):
 
 fetch, write, sq = pmc('pmc_fetch'), pmc('pmc_write'), pmc('pmc_sq')
 summary = {}
-for k in ('k_mlp_gemm', 'k_sample', 'k_last_layer'):
+GEMM = 'k_mlp_gemm_buf' if 'k_mlp_gemm_buf' in fetch else 'k_mlp_gemm'
+for k in (GEMM, 'k_sample_col', 'k_expand', 'k_last_layer'):
     f = fetch.get(k, {}).get('FETCH_SIZE', [])
     w = write.get(k, {}).get('WRITE_SIZE', [])
     if f and w:
@@ -49,11 +50,12 @@ for k in ('k_mlp_gemm', 'k_sample', 'k_last_layer'):
         wb = 1024.0 * sum(w) / len(w)
         summary[k] = {'launches': len(f), 'fetch_bytes_per_launch_corrected': fb, 'write_bytes_per_launch': wb,
                       'hbm_bytes_per_launch': fb + wb}
-g = sq.get('k_mlp_gemm', {})
+g = sq.get(GEMM, {})
 if g:
-    summary['k_mlp_gemm_sq'] = {c: sum(v) / len(v) for c, v in g.items()}
+    summary[GEMM + '_sq'] = {c: sum(v) / len(v) for c, v in g.items()}
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --res 128 '
                      '(same per-launch geometry as the headline run: 51 chunks x 5120 rows)',
-           'k_mlp_gemm_hbm_bytes_per_launch': summary.get('k_mlp_gemm', {}).get('hbm_bytes_per_launch'),
+           'gemm_kernel': GEMM,
+           'k_mlp_gemm_hbm_bytes_per_launch': summary.get(GEMM, {}).get('hbm_bytes_per_launch'),
            'detail': summary}, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(summary, indent=1))
