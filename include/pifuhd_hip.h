@@ -162,6 +162,12 @@ int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream
 int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
                      float *normals, pifu_stream stream);
 
+/* The colour loop of gen_mesh (reconstruction.py:58-70) in one call: identical to pifu_calc_normal on consecutive
+ * slices of `verts_per_call` vertices (the last one shorter) - every slice is its own GroupNorm batch - but several
+ * slices share one kernel launch. */
+int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
+                             float delta, float *normals, pifu_stream stream);
+
 /* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
  * reconstruction.py:112-115): bilinear grid_sample, align_corners=True, zero padding.
  * feat: device fp32 NCHW [C][H][W] (batch 1); uv: device fp32 [2][n]; out: device fp32 [C][n]. */

@@ -1759,6 +1759,9 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     PIFU_REQUIRE(P <= (int64_t)1 << 30, PIFU_ERR_NOMEM, "chunk of %lld points is too large", (long long)eff_chunk);
     const int64_t total_chunks = (n + chunk - 1) / chunk;
     int64_t target_rows = ctx->ws_rows > 0 ? ctx->ws_rows : 262144;
+    // calc_normal chunks are 200 000 rows: one per launch leaves the 128-column layers with 3.05 rounds of resident
+    // blocks; four per launch fill the chip evenly (about 12.5 KB of workspace per row)
+    if (src_mode == 3 && target_rows < 4 * P && 4 * P <= ((int64_t)1 << 20)) target_rows = 4 * P;
     int64_t batch_chunks = target_rows / P;
     if (batch_chunks < 1) batch_chunks = 1;
     if (batch_chunks > total_chunks) batch_chunks = total_chunks;
@@ -1881,6 +1884,21 @@ int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *
     PIFU_REQUIRE(n > 0, PIFU_ERR_INVALID, "pifu_calc_normal: empty vertex batch (the reference raises here too)");
     float *pred4 = nullptr;
     int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * n, PIFU_Q_NO_FINE_MASK,
+                             nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
+    if (rc != PIFU_OK) return rc;
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)pred4, n, normals);
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
+                             float delta, float *normals, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && verts && calib && normals, PIFU_ERR_INVALID, "pifu_calc_normal_chunked: null argument");
+    PIFU_REQUIRE(n > 0 && verts_per_call > 0, PIFU_ERR_INVALID, "pifu_calc_normal_chunked: empty vertex batch");
+    float *pred4 = nullptr;
+    int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * verts_per_call, PIFU_Q_NO_FINE_MASK,
                              nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
     if (rc != PIFU_OK) return rc;
     hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -154,3 +154,21 @@ def sharded_calls(spans, call_fn, width, device, group=None):
             out[l:r] = full[row:row + (r - l)]
             row += r - l
     return out
+
+
+def gather_runs(runs, mine, run_fn, width, device, group=None):
+    """`runs`: one contiguous row range (left, right) per rank that has work, ascending; `mine`: this rank's run (list of
+    0 or 1 entries); run_fn(left, right) -> float32 [right-left, width].  One all-gather; returns [runs[-1][1], width]."""
+    import torch.distributed as dist
+    rank, ws = world()
+    n_rows = runs[-1][1] if runs else 0
+    slot_rows = max(max((r - l) for (l, r) in runs), 1) if runs else 1
+    local = torch.zeros(slot_rows, width, device=device, dtype=torch.float32)
+    for (l, r) in mine:
+        local[:r - l] = run_fn(l, r)
+    full = torch.empty(ws * slot_rows, width, device=device, dtype=torch.float32)
+    dist.all_gather_into_tensor(full, local, group=group)
+    out = torch.zeros(n_rows, width, device=device, dtype=torch.float32)
+    for rk, (l, r) in enumerate(runs):          # ranks with work are the first len(runs) ranks (shard_range is monotone)
+        out[l:r] = full[rk * slot_rows: rk * slot_rows + (r - l)]
+    return out

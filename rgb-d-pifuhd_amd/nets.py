@@ -451,6 +451,22 @@ class PIFuMRNet(BasePIFuNet):
                   _stream_ptr(self.device))
         self.nmls = out[None]
 
+    def calc_normal_chunked(self, points, calib_local, calib_global, interval=50000, delta=0.001):
+        """The colour loop of `gen_mesh` (`reconstruction.py:58-70`) in one call: the same numbers as `calc_normal` on
+        consecutive `interval`-vertex slices of points [1,1,3,n] (each slice its own GroupNorm batch) -> self.nmls [1,3,n]."""
+        pts = points.to(self.device, torch.float32)
+        if pts.dim() != 4 or pts.shape[0] != 1 or pts.shape[1] != 1 or pts.shape[2] != 3:
+            raise NotImplementedError('points [1,1,3,n] (single view, the reconstruction path)')
+        pts = pts[0, 0].contiguous()
+        n = pts.shape[1]
+        if n == 0:
+            raise RuntimeError('calc_normal on an empty vertex slice')
+        calib, calib_p = _host_f32(calib_global[0])
+        out = torch.empty(3, n, device=self.device, dtype=torch.float32)
+        _lib.call('pifu_calc_normal_chunked', self._ctx.h, _ptr(pts), n, int(interval), calib_p, float(delta), _ptr(out),
+                  _stream_ptr(self.device))
+        self.nmls = out[None]
+
     def get_im_feat(self):
         return self.im_feat_list[-1]
 

@@ -20,18 +20,26 @@ from .mesh_util import reconstruction, save_obj_mesh_with_color
 from .nets import index
 
 
-def _save_debug_png(path, image_tensor_global):
-    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`)."""
+def _save_debug_png(path, image_tensor_global, background=False):
+    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`).  The pixels are fetched here; with
+    `background=True` the PNG encoding (zlib, GIL released) runs on a thread that the caller joins before returning."""
     try:
         from PIL import Image
     except Exception:          # pragma: no cover - PIL is optional plumbing
-        return False
-    tiles = []
-    for v in range(image_tensor_global.shape[0]):
-        arr = np.transpose(image_tensor_global[v].detach().cpu().numpy(), (1, 2, 0)) * 0.5 + 0.5
-        tiles.append(np.clip(np.rint(arr[:, :, :3] * 255.0), 0, 255).astype(np.uint8))
-    Image.fromarray(np.concatenate(tiles, axis=1)).save(path)
-    return True
+        return None
+    strip = torch.cat([image_tensor_global[v, :3] for v in range(image_tensor_global.shape[0])], 2)      # [3, H, n*W]
+    arr = (strip.detach().permute(1, 2, 0) * 0.5 + 0.5) * 255.0
+    tiles = np.clip(np.rint(arr.cpu().numpy()), 0, 255).astype(np.uint8)
+
+    def encode():
+        Image.fromarray(tiles).save(path, compress_level=1)      # cv2.imwrite's default PNG compression level is 1 too
+    if not background:
+        encode()
+        return None
+    import threading
+    th = threading.Thread(target=encode)
+    th.start()
+    return th
 
 
 def _normal_spans(n_verts, interval=50000):
@@ -79,8 +87,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         pass
     b_min = data['b_min']
     b_max = data['b_max']
-    if rank == 0:
-        _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
+    png_thread = _save_debug_png(save_path[:-4] + '.png', image_tensor_global, background=True) if rank == 0 else None
     t2 = mark()
 
     # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
@@ -95,21 +102,28 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
         raise RuntimeError('calc_normal on an empty vertex slice')
 
+    # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
+    # (`reconstruction.py:58-70`), several of them per kernel launch
     def normals_of(left, right):
-        net.calc_normal(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor)
+        net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=50000)
         return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
 
-    color32 = pdist.sharded_calls(spans, normals_of, 3, dev) if ws > 1 else None
-    if color32 is None:
-        color32 = torch.zeros(spans[-1][1], 3, device=dev, dtype=torch.float32)
-        for (l, r) in spans:
-            color32[l:r] = normals_of(l, r)
+    if ws > 1:
+        i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
+        mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
+        runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
+                (pdist.shard_range(len(spans), ws, rk)[:2] for rk in range(ws)) if j1 > j0]
+        color32 = pdist.gather_runs(runs, mine, normals_of, 3, dev)
+    else:
+        color32 = normals_of(0, spans[-1][1])
     color = np.zeros(verts.shape)
     color[:color32.shape[0]] = color32.cpu().numpy()
     t4 = mark()
 
     if rank == 0:
         save_obj_mesh_with_color(save_path, verts, faces, color)
+    if png_thread is not None:
+        png_thread.join()
     t5 = time.perf_counter()
     if timings is not None:
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,

@@ -107,6 +107,22 @@ def test_calc_normal(gold):
     assert np.allclose(np.linalg.norm(n, axis=0), 1.0, atol=1e-5)
 
 
+def test_calc_normal_chunked_equals_per_call():
+    """pifu_calc_normal_chunked = pifu_calc_normal on consecutive slices (each slice one GroupNorm batch), bit for bit."""
+    netG, netMR, *_ = _build()
+    calib = calib_tensor()
+    pts = seeded_points(8, 1000, lim=0.9).cuda()
+    netMR.calc_normal_chunked(pts[:, None], calib[:, None], calib, interval=300)        # 300, 300, 300, 100
+    got = netMR.nmls[0].clone()
+    want = []
+    for l in range(0, 1000, 300):
+        netMR.calc_normal(pts[:, None, :, l:l + 300], calib[:, None], calib)
+        want.append(netMR.nmls[0].clone())
+    assert torch.equal(got, torch.cat(want, 1))
+    netMR.calc_normal(pts[:, None], calib[:, None], calib)                              # one 1000-vertex batch differs
+    assert not torch.equal(got, netMR.nmls[0])
+
+
 def test_errors_are_loud():
     from pifuhd_amd import _lib, config, nets
     oc = config.coarse_opt()
