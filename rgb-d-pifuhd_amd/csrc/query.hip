@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
 // VALU instruction of the staging path, the column-init gather and the epilogue is matrix time lost.  All global
 // accesses here are `buffer_load/store ... s[rsrc], soffset offen`: a uniform (SGPR) tile descriptor + a per-lane 32-bit
 // byte offset + a scalar offset, so no 64-bit vector address arithmetic is left; the norm + LeakyReLU transform runs on
-// packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).  Same tiles, same LDS layout, same MFMA and summation order as
+// packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), and the operand segment of a K step comes from a cursor that is re-resolved
+// only when it enters the next segment.  Same tiles, same LDS layout, same MFMA and summation order as
 // k_mlp_gemm<32, 4>: bit-identical results.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -404,8 +405,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
 
     const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
     const unsigned kb = kq * 16;
-    const int b1 = a.seg[0].width;
-    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
     const int nsteps = a.ldw / TBK;
     const unsigned ldw4 = (unsigned)a.ldw * 4u;
     const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
@@ -414,32 +413,47 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
     float rslope = 1.f;
 
+    // cursor of the next K step to fetch: every per-segment quantity is resolved when the cursor ENTERS a segment (a rare
+    // uniform branch), so a step costs a handful of scalar adds instead of a ~70-instruction select chain
+    int c_seg = 0, c_left = a.seg[0].width / TBK;
+    unsigned c_ks4 = 0, c_kw4 = 0;
+    unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
+    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0 * (size_t)a.seg[0].ld);
+    __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
+    __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
+    float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
+    unsigned voA = (unsigned)sr * c_ld4 + kb;
 #define BUF_GLOAD(step_)                                                                                   \
     {                                                                                                      \
-        const int kk = (step_) * TBK;                                                                      \
-        const int sg = (kk >= b1) + (kk >= b2);                                                            \
-        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
-        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
-        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
-        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
-        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
-        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
-        rslope = md == 0 ? 1.f : 0.01f;                                                                    \
-        const unsigned ks4 = (unsigned)(kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2))) * 4u;                    \
-        const unsigned ld4 = (unsigned)ld * 4u;                                                            \
-        const __amdgpu_buffer_rsrc_t rA = buf_rsrc(ptr + row0 * (size_t)ld);                               \
-        const unsigned voA = (unsigned)sr * ld4 + kb;                                                      \
-        ra0 = buf_load4(rA, voA, ks4);                                                                     \
-        ra1 = buf_load4(rA, voA, ks4 + 32u * ld4);                                                         \
-        ra2 = buf_load4(rA, voA, ks4 + 64u * ld4);                                                         \
-        ra3 = buf_load4(rA, voA, ks4 + 96u * ld4);                                                         \
-        rsc = buf_load4(buf_rsrc(sc + (size_t)chunk_id * sld), kb, ks4);                                   \
-        rsh = buf_load4(buf_rsrc(sh + (size_t)chunk_id * sld), kb, ks4);                                   \
-        const unsigned kw4 = (unsigned)kk * 4u;                                                            \
-        rw0 = buf_load4(rW, voW, kw4);                                                                     \
-        rw1 = buf_load4(rW, voW, kw4 + 32u * ldw4);                                                        \
-        rw2 = buf_load4(rW, voW, kw4 + 64u * ldw4);                                                        \
-        rw3 = buf_load4(rW, voW, kw4 + 96u * ldw4);                                                        \
+        rslope = c_slope;                                                                                  \
+        ra0 = buf_load4(c_rA, voA, c_ks4);                                                                 \
+        ra1 = buf_load4(c_rA, voA, c_ks4 + 32u * c_ld4);                                                   \
+        ra2 = buf_load4(c_rA, voA, c_ks4 + 64u * c_ld4);                                                   \
+        ra3 = buf_load4(c_rA, voA, c_ks4 + 96u * c_ld4);                                                   \
+        rsc = buf_load4(c_rsc, kb, c_ks4);                                                                 \
+        rsh = buf_load4(c_rsh, kb, c_ks4);                                                                 \
+        rw0 = buf_load4(rW, voW, c_kw4);                                                                   \
+        rw1 = buf_load4(rW, voW, c_kw4 + 32u * ldw4);                                                      \
+        rw2 = buf_load4(rW, voW, c_kw4 + 64u * ldw4);                                                      \
+        rw3 = buf_load4(rW, voW, c_kw4 + 96u * ldw4);                                                      \
+        c_ks4 += TBK * 4u;                                                                                 \
+        c_kw4 += TBK * 4u;                                                                                 \
+        if (--c_left == 0 && ++c_seg < a.nseg) {                                                           \
+            const float *np_ = c_seg == 1 ? a.seg[1].ptr : a.seg[2].ptr;                                   \
+            const float *nsc_ = c_seg == 1 ? a.seg[1].scale : a.seg[2].scale;                              \
+            const float *nsh_ = c_seg == 1 ? a.seg[1].shift : a.seg[2].shift;                              \
+            const int nld_ = c_seg == 1 ? a.seg[1].ld : a.seg[2].ld;                                       \
+            const int nsld_ = c_seg == 1 ? a.seg[1].sld : a.seg[2].sld;                                    \
+            const int nmd_ = c_seg == 1 ? a.seg[1].mode : a.seg[2].mode;                                   \
+            c_left = (c_seg == 1 ? a.seg[1].width : a.seg[2].width) / TBK;                                 \
+            c_ks4 = 0;                                                                                     \
+            c_ld4 = (unsigned)nld_ * 4u;                                                                   \
+            c_rA = buf_rsrc(np_ + row0 * (size_t)nld_);                                                    \
+            c_rsc = buf_rsrc(nsc_ + (size_t)chunk_id * nsld_);                                             \
+            c_rsh = buf_rsrc(nsh_ + (size_t)chunk_id * nsld_);                                             \
+            c_slope = nmd_ == 0 ? 1.f : 0.01f;                                                             \
+            voA = (unsigned)sr * c_ld4 + kb;                                                               \
+        }                                                                                                  \
     }
     // norm affine + LeakyReLU on packed pairs: t = v * sc + sh;  v = max(t, slope * t)
 #define BUF_XF(va_)                                                                                        \
