@@ -50,6 +50,10 @@ struct ConvArgs {
     int ldr;
     int cout;               // valid output channels
     int ntm, ntn;
+    // split-K (launches with too few tiles to fill the chip): split s accumulates K steps [s * steps_per_split, ...) into
+    // part[s][row][col] (raw, no bias); k_conv_splitk_reduce sums the splits in order and applies the epilogue
+    int nsplit, steps_per_split, tiles_per_split;
+    float *part;            // [nsplit][ntm * BM][ntn * BN]
 };
 
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
@@ -57,14 +61,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = blockIdx.x / a.tiles_per_split, bt = blockIdx.x - split * a.tiles_per_split;
+    const int xcd = bt & 7, slot = bt >> 3;
     const int tile_n = slot % a.ntn;
     const int tile_m = (slot / a.ntn) * 8 + xcd;
     if (tile_m >= a.ntm) return;
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     const int kq = tid & 7, sr = tid >> 3;
     const int ldw = a.ntaps * a.cin;
-    const int nsteps = ldw / BK;
+    const int step_lo = split * a.steps_per_split;
+    const int step_hi = min(ldw / BK, step_lo + a.steps_per_split);
 
     // the 4 rows this thread stages: logical (ry, rx) -> input base pixel
     int by0, bx0, by1, bx1, by2, bx2, by3, bx3;
@@ -130,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
     }
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    CONV_GLOAD(0)
+    CONV_GLOAD(step_lo)
     CONV_LSTORE(0)
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
+    for (int step = step_lo; step < step_hi; ++step) {
+        const int buf = (step - step_lo) & 1;
+        const bool more = step + 1 < step_hi;
         if (more) CONV_GLOAD(step + 1)
         const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
         const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
@@ -162,6 +168,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
     }
 
     const int h = lane >> 5, j = lane & 31;
+    if (a.nsplit > 1) {     // raw partial tile; rows / columns beyond the valid range are written too (never read)
+        float *P = a.part + ((size_t)split * a.ntm * BM + row0) * ((size_t)a.ntn * BN) + col0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    P[(size_t)(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ((size_t)a.ntn * BN) + wn * 64 + nt * 32 + j] = acc[r];
+            }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = col0 + wn * 64 + nt * 32 + j;
@@ -181,6 +200,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
                     a.Y[pix * a.ldy + col] = v;
                 }
             }
+        }
+    }
+}
+
+// split-K epilogue: Y = sum_s part[s] (fixed order) + bias (+ residual), with the conv's output pixel mapping
+__global__ void k_conv_splitk_reduce(const ConvArgs a)
+{
+    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) % (a.ntn * BN / 4);
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) / (a.ntn * BN / 4);
+    if (row >= a.nrows || c4 * 4 >= a.cout) return;
+    const size_t ldp = (size_t)a.ntn * BN, plane = (size_t)a.ntm * BM * ldp;
+    float4 v = *reinterpret_cast<const float4 *>(a.part + (size_t)row * ldp + c4 * 4);
+    for (int s = 1; s < a.nsplit; ++s) {
+        const float4 p = *reinterpret_cast<const float4 *>(a.part + s * plane + (size_t)row * ldp + c4 * 4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int ry = row / a.RW, rx = row - ry * a.RW;
+    const size_t pix = (size_t)(ry * a.os + a.oy0) * a.Wout + (rx * a.os + a.ox0);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = c4 * 4 + k;
+        if (col < a.cout) {
+            float o = vv[k] + a.bias[col];
+            if (a.R) o += a.R[pix * a.ldr + col];
+            a.Y[pix * a.ldy + col] = o;
         }
     }
 }
@@ -454,6 +499,7 @@ struct EncState {
     std::map<std::string, HostParam> params;
     std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
     DevBuf arena;
+    DevBuf splitk;                               // partial tiles of split-K convolutions (reused, stream-ordered)
     size_t used = 0;
     hipStream_t st = nullptr;
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
@@ -549,7 +595,10 @@ Affine norm_affine(EncState &S, const std::string &prefix, const Tensor &x, int 
     const int groups = norm == 2 ? 32 : C;
     const int cpg = C / groups;
     const int P = (int)x.pixels();
-    int rows_per_block = 1024;
+    // ~256 blocks in flight: small maps (32 x 32 x 1024 channels) would otherwise be reduced by a single block
+    int rows_per_block = (P + 255) / 256;
+    if (rows_per_block < 8) rows_per_block = 8;
+    if (rows_per_block > 1024) rows_per_block = 1024;
     const int nb = (P + rows_per_block - 1) / rows_per_block;
     double *partial = reinterpret_cast<double *>(arena_take(S, (size_t)nb * C * 2 * 2));
     const int cg = C / 4;
@@ -623,8 +672,30 @@ void launch_conv(EncState &S, ConvArgs a)
 {
     a.ntm = (a.nrows + BM - 1) / BM;
     a.ntn = (a.cout + BN - 1) / BN;
-    const int nblocks = (int)round_up(a.ntm, 8) * a.ntn;
-    hipLaunchKernelGGL(k_conv_gemm, dim3(nblocks), dim3(256), 0, S.st, a);
+    const int tiles = (int)round_up(a.ntm, 8) * a.ntn;
+    const int nsteps = a.ntaps * a.cin / BK;
+    // fewer than ~1 tile per CU: split K so that ~512 blocks are in flight, at least 8 K steps per split
+    int nsplit = 1;
+    if (a.ntm * a.ntn < 192) {
+        nsplit = (512 + a.ntm * a.ntn - 1) / (a.ntm * a.ntn);
+        if (nsplit > nsteps / 8) nsplit = nsteps / 8;
+        if (nsplit < 1) nsplit = 1;
+    }
+    a.steps_per_split = (nsteps + nsplit - 1) / nsplit;
+    nsplit = (nsteps + a.steps_per_split - 1) / a.steps_per_split;
+    a.nsplit = nsplit;
+    a.tiles_per_split = tiles;
+    a.part = nullptr;
+    if (nsplit > 1) {
+        const size_t bytes = (size_t)nsplit * a.ntm * BM * a.ntn * BN * sizeof(float);
+        if (pifu_ensure(S.splitk, bytes) != PIFU_OK) throw Fail{"split-K workspace allocation failed"};
+        a.part = static_cast<float *>(S.splitk.p);
+    }
+    hipLaunchKernelGGL(k_conv_gemm, dim3(tiles * nsplit), dim3(256), 0, S.st, a);
+    if (nsplit > 1) {
+        const size_t threads = (size_t)a.nrows * (a.ntn * BN / 4);
+        hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.st, a);
+    }
 }
 
 // y (a channel slice of `out`) = conv(act(x)); out must have the conv's output size
@@ -877,6 +948,7 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
     (void)hipDeviceSynchronize();
     for (auto &kv : it->second->dev) (void)hipFree(kv.second);
     if (it->second->arena.p) (void)hipFree(it->second->arena.p);
+    if (it->second->splitk.p) (void)hipFree(it->second->splitk.p);
     delete it->second;
     g_states.erase(it);
     return PIFU_OK;
@@ -893,7 +965,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_coarse: bad norm / hg_dim");
     EncState &S = state_of(ctx);
     const size_t px = (size_t)H * W;
-    int rc = begin(ctx, S, px * 4 * (size_t)(2600 + 700 * num_stack) + ((size_t)64 << 20), (hipStream_t)stream);
+    int rc = begin(ctx, S, px * 4 * (size_t)(2600 + 700 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
     if (rc) return rc;
     try {
         if (use_front || use_back) {
@@ -938,7 +1010,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_fine: bad norm / hg_dim");
     EncState &S = state_of(ctx);
     const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
-    int rc = begin(ctx, S, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)64 << 20), (hipStream_t)stream);
+    int rc = begin(ctx, S, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
     if (rc) return rc;
     try {
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
