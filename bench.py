@@ -33,39 +33,54 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 
 def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     """gen_mesh wall time on N GPUs: (a) ONE subject, grid evaluation + colour loop sharded (max over ranks);
-    (b) N subjects, one per GPU, no communication (time for all N to finish)."""
+    (b) N subjects, one per GPU, no communication (time for all N to finish).  Every rank always takes part in every
+    collective, also after a local failure (reported as an error string), so a bad subject cannot hang the job."""
     import tempfile
     import torch
     from pifuhd_amd import reconstruction as recon
     res = {'resolution': args.genmesh_res, 'use_octree': True, 'n_gpus': world}
+    keys = ('filter_s', 'png_s', 'reconstruction_s', 'normals_s', 'obj_s')
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
     with tempfile.TemporaryDirectory() as td:
+        # (a) sharded: identical inputs on every rank, so a failure is the same on every rank
+        timings, err, t_tot = {}, None, float('inf')
         try:
             recon.gen_mesh(128, netMR, dev, data, os.path.join(td, f'warm{rank}.obj'), sharded=True)
             fence()
-            timings = {}
             t0 = time.perf_counter()
-            recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'mesh{rank}.obj'), timings=timings,
-                           sharded=True)
+            recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'mesh{rank}.obj'), timings=timings, sharded=True)
             fence()
-            t = torch.tensor([time.perf_counter() - t0] + [timings[k] for k in
-                             ('filter_s', 'png_s', 'reconstruction_s', 'normals_s', 'obj_s')], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            res['one_subject_sharded'] = {'total_s': round(float(t[0]), 4), 'filter_s': round(float(t[1]), 4),
-                                          'png_s': round(float(t[2]), 4), 'reconstruction_s': round(float(t[3]), 4),
-                                          'normals_s': round(float(t[4]), 4), 'obj_s': round(float(t[5]), 4),
-                                          'n_verts': timings['n_verts'], 'n_faces': timings['n_faces']}
-            log(f"gen_mesh sharded: {float(t[0]):.3f} s")
+            t_tot = time.perf_counter() - t0
+        except Exception as e:
+            err = repr(e)
+        red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
+        if err is None and red[0] != float('inf'):
+            res['one_subject_sharded'] = {'total_s': round(red[0], 4), **{k: round(v, 4) for k, v in zip(keys, red[1:])},
+                                          'n_verts': timings.get('n_verts'), 'n_faces': timings.get('n_faces')}
+            log(f"gen_mesh sharded: {red[0]:.3f} s")
+        else:
+            res['one_subject_sharded'] = {'error': err or 'failed on another rank'}
+        # (b) independent subjects (different images: a failure may be local to one rank)
+        err, t_tot = None, float('inf')
+        try:
             own = synth.synthetic_inputs(1024, 3, seed=rank)
-            fence()
+            torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subj{rank}.obj'))
-            fence()
-            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            res['independent_subjects'] = {'subjects': world, 'total_s': round(float(t[0]), 4),
-                                           'subjects_per_s': round(world / float(t[0]), 3)}
+            torch.cuda.synchronize(dev)
+            t_tot = time.perf_counter() - t0
         except Exception as e:
-            res['error'] = repr(e)
+            err = repr(e)
+        red = reduce_max([t_tot])
+        if red[0] != float('inf'):
+            res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3)}
+        else:
+            res['independent_subjects'] = {'error': err or 'failed on another rank'}
     return res
 
 
@@ -105,11 +120,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
-    dev = torch.device('cuda', local_rank)
+    # PIFU_BENCH_ONE_GPU=1 is a functional test hook: all ranks share cuda:0 and talk over gloo (RCCL refuses two ranks
+    # on one device), so the N > 1 code path can be exercised on a single-GPU box; never a measurement
+    one_gpu_test = os.environ.get('PIFU_BENCH_ONE_GPU') == '1'
+    dev = torch.device('cuda', 0 if one_gpu_test else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu_test:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     # ---- model + inputs (outside the timed region) ---------------------------------------------------
     oc = config.coarse_opt()
@@ -209,9 +230,9 @@ def main():
             'flop_per_query_canonical': FLOP_PER_QUERY,
             # what the GEMM launches of the timed region actually executed (column sharing removes the per-point
             # image-feature products: 2 163 200 FLOP per query + the per-column tables)
-            'gemm_flop_per_query_executed': round(gemm_flops.value / max(total * args.steps, 1)),
+            'gemm_flop_per_query_executed': round(gemm_flops.value * world / max(total * args.steps, 1)),   # rank 0's launches x N
         },
-        'executed_gemm_tflops_over_step': round(gemm_flops.value / elapsed / 1e12, 2),
+        'executed_gemm_tflops_over_step': round(gemm_flops.value * world / elapsed / 1e12, 2),
         'canonical_equivalent_tflops': round(value * 1e6 * FLOP_PER_QUERY / 1e12, 2),
         'roofline': {
             'kernel': 'k_mlp_gemm_buf', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
