@@ -160,6 +160,24 @@ class OracleNets:
         self.preds = inside * pred if mask_fine else pred
         return self.preds
 
+    # ---- f4: supervised forward (PIFuMRNet.py:157-186,253-288; PIFuNetwNML.py:119-120) --------
+    def query_supervised(self, points, calib, labels):
+        """`query(points, calib, labels=labels)` + `get_error()` with CustomBCELoss: returns the attributes the
+        reference leaves behind (labels, w, gamma, preds, preds_low) and Err(occ:fine)."""
+        xyz = orthogonal(points, calib)
+        xy = xyz[:, :2, :]
+        inside = ((xy >= -1) & (xy <= 1)).all(dim=1, keepdim=True).float()
+        preds = self.query(points, calib)
+        newlabels = inside * labels                                                   # PIFuMRNet.py:158
+        w = inside.size(2) / inside.view(inside.size(0), -1).sum(1)                   # :160
+        gamma = 1 - newlabels.view(newlabels.size(0), -1).sum(1) / inside.view(inside.size(0), -1).sum(1)   # :161-162
+        preds_low = self.preds_coarse[None]
+        # get_error (PIFuMRNet.py:267-270) evaluates the loss on preds_low for every fine stack (sic)
+        err = custom_bce_loss(preds_low[0], newlabels, gamma, w)
+        xyz_in = ((xyz >= -1) & (xyz <= 1)).all(dim=1, keepdim=True).float()
+        return {'preds': preds, 'preds_low': preds_low, 'labels': newlabels, 'w': w, 'gamma': gamma,
+                'err_fine': err, 'coarse_labels': xyz_in * labels}
+
     # ---- A17 ------------------------------------------------------------------------------
     def calc_normal(self, points, calib, delta=0.001):
         """Forward differences (`PIFuMRNet.py:188-243`); points [1,3,n] -> [1,3,n]."""
@@ -201,6 +219,22 @@ class OracleNets:
                             'no_down', bn_training=self.fine_training)
         self.feat_fine = outs[-1]
         return self.feat_fine
+
+
+def custom_bce_loss(pred, gt, gamma, w=None, brock=False, fixed_gamma=None):
+    """`CustomBCELoss.forward` (`net_util.py:45-66`)."""
+    x_hat = torch.clamp(pred, 1e-5, 1.0 - 1e-5)
+    g = gamma[:, None, None] if fixed_gamma is None else fixed_gamma
+    if brock:
+        x = 3.0 * gt - 1.0
+        loss = -(g * x * torch.log(x_hat) + (1.0 - g) * (1.0 - x) * torch.log(1.0 - x_hat))
+    else:
+        loss = -(g * gt * torch.log(x_hat) + (1.0 - g) * (1.0 - gt) * torch.log(1.0 - x_hat))
+    if w is not None:
+        if w.dim() == 1:
+            w = w[:, None, None]
+        return (loss * w).mean()
+    return loss.mean()
 
 
 # =============================================================================== A7 (HGFilter)

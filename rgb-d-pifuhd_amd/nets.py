@@ -157,11 +157,9 @@ class BasePIFuNet:
         return self.train(False)
 
     @staticmethod
-    def _check_unsupported(transforms, labels):
+    def _check_unsupported(transforms, labels=None):
         if transforms is not None:
             raise NotImplementedError('screen-space `transforms` are never used on the reconstruction path')
-        if labels is not None:
-            raise NotImplementedError('`labels` (training supervision) is out of scope of the HIP path')
 
 
 class PIFuNetwNML(BasePIFuNet):
@@ -292,6 +290,10 @@ class PIFuNetwNML(BasePIFuNet):
         phi = torch.empty(cphi, n, device=self.device, dtype=torch.float32) if update_phi else None
         _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, _lib.Q_COARSE_ONLY, None, _ptr(pred),
                   _ptr(phi), _stream_ptr(self.device))
+        if labels is not None:                                  # PIFuNetwNML.py:115-120: in-box over x, y and z
+            xyz = self.projection(pts, calibs.to(self.device, torch.float32))
+            in_bb = ((xyz >= -1) & (xyz <= 1)).all(dim=1, keepdim=True).float()
+            self.labels = in_bb * labels.to(self.device, torch.float32)
         if update_phi:
             self.phi = phi[None]
         if update_pred:
@@ -302,11 +304,18 @@ class PIFuNetwNML(BasePIFuNet):
 class PIFuMRNet(BasePIFuNet):
     """Fine level (`PIFuMRNet.py:15-243`); owns a reference to the coarse net `netG`."""
 
-    def __init__(self, opt, netG, projection_mode='orthogonal'):
+    def __init__(self, opt, netG, projection_mode='orthogonal', criteria=None):
         super().__init__(projection_mode)
         self.name = 'hg_pifu'
         self.opt = opt
         self.netG = netG
+        # the reference's default {'occ': nn.MSELoss()} cannot take get_error's (pred, gt, gamma, w) call; its training
+        # script passes CustomBCELoss (train.py), which is the default here
+        from .net_util import CustomBCELoss
+        self.criteria = criteria if criteria is not None else {'occ': CustomBCELoss()}
+        self.w = None
+        self.gamma = None
+        self.labels_nml = None
         self._ctx = netG._ctx
         self.device = netG.device
         self._sd = None
@@ -432,11 +441,50 @@ class PIFuMRNet(BasePIFuNet):
         self.preds = fine[None, None]
         self.preds_interm = self.preds[None]
         self.preds_low = g.preds[None]
+        if labels is not None:                                  # PIFuMRNet.py:157-162,183-186
+            lab = labels.to(self.device, torch.float32)
+            if lab.dim() == 4:
+                lab = lab[:, 0]
+            xyz = self.projection(pts, calib_local.to(self.device, torch.float32))
+            in_bb = ((xyz[:, :2] >= -1) & (xyz[:, :2] <= 1)).all(dim=1, keepdim=True).float()
+            self.labels = in_bb * lab
+            self.w = in_bb.size(2) / in_bb.view(in_bb.size(0), -1).sum(1)
+            self.gamma = 1 - self.labels.view(self.labels.size(0), -1).sum(1) / in_bb.view(in_bb.size(0), -1).sum(1)
+
+    def get_error(self):
+        """`PIFuMRNet.get_error` (`PIFuMRNet.py:253-274`), including its use of `preds_low` in the fine term."""
+        error = {}
+        if getattr(self.opt, 'train_full_pifu', False) and not getattr(self.opt, 'no_intermediate_loss', False):
+            error['Err(occ)'] = 0.0
+            for i in range(self.preds_low.size(0)):
+                error['Err(occ)'] += self.criteria['occ'](self.preds_low[i], self.labels, self.gamma, self.w)
+            error['Err(occ)'] /= self.preds_low.size(0)
+        error['Err(occ:fine)'] = 0.0
+        for i in range(self.preds_interm.size(0)):
+            error['Err(occ:fine)'] += self.criteria['occ'](self.preds_low[i], self.labels, self.gamma, self.w)
+        error['Err(occ:fine)'] /= self.preds_interm.size(0)
+        if self.nmls is not None and self.labels_nml is not None:
+            error['Err(nml:fine)'] = self.criteria['nml'](self.nmls, self.labels_nml)
+        return error
+
+    def forward(self, images_local, images_global, points, calib_local, calib_global, labels, points_nml=None,
+                labels_nml=None, rect=None):
+        """`PIFuMRNet.forward` (`PIFuMRNet.py:276-288`): forward-only (no autograd on the HIP path) -> (err, res)."""
+        self.filter_global(images_global)
+        self.filter_local(images_local, rect)
+        self.query(points, calib_local, calib_global, labels=labels)
+        if points_nml is not None and labels_nml is not None:
+            self.calc_normal(points_nml, calib_local, calib_global, labels=labels_nml)
+        return self.get_error(), self.get_preds()
+
+    __call__ = forward
 
     def calc_normal(self, points, calib_local, calib_global, transforms=None, labels=None, delta=0.001,
                     fd_type='forward'):
         """`PIFuMRNet.calc_normal` (`PIFuMRNet.py:188-243`): points [1,1,3,n] -> self.nmls [1,3,n]."""
-        self._check_unsupported(transforms, labels)
+        self._check_unsupported(transforms)
+        if labels is not None:
+            self.labels_nml = labels
         pts = points.to(self.device, torch.float32)
         if pts.dim() != 4 or pts.shape[0] != 1 or pts.shape[1] != 1 or pts.shape[2] != 3:
             raise NotImplementedError('points [1,1,3,n] (single view, the reconstruction path)')

@@ -203,3 +203,34 @@ def test_split_precision_bf16x3_within_contract(gold):
         _lib.call('pifu_set_precision', netMR._ctx.h, 0)
     netMR.query(seeded_points(3, 700), calib)
     assert np.array_equal(netMR.get_preds()[0, 0].cpu().numpy(), exact)
+
+
+def test_supervised_forward_matches_reference():
+    """query(labels=...) + get_error() (forward only) against the reference fixture."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'labels_small.npz'))
+    from pifuhd_amd import nets
+    from pifuhd_amd.net_util import CustomBCELoss
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(3)
+    netG.set_features(fc); netMR.set_features(ff)
+    seed, n = [int(v) for v in gold['seed']]
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(1, 3, n, generator=g) * 2.3 - 1.15
+    labels = (torch.rand(1, 1, n, generator=g) > 0.5).float()
+    calib = calib_tensor()
+    netMR.query(pts, calib, labels=labels)
+    err = netMR.get_error()
+    assert np.array_equal(netMR.labels.cpu().numpy(), gold['labels'])
+    assert np.allclose(netMR.w.cpu().numpy(), gold['w'], rtol=1e-6) and np.allclose(netMR.gamma.cpu().numpy(), gold['gamma'], rtol=1e-6)
+    assert np.abs(netMR.preds.cpu().numpy() - gold['preds']).max() < 1e-4
+    assert np.abs(netMR.preds_low.cpu().numpy() - gold['preds_low']).max() < 1e-4
+    assert abs(float(err['Err(occ:fine)']) - float(gold['err_fine'][0])) < 1e-4
+    netG.query(pts, calib, labels=labels)
+    assert np.array_equal(netG.labels.cpu().numpy(), gold['coarse_labels'])
+    pred, gt = torch.from_numpy(gold['loss_in'][0]).cuda(), torch.from_numpy(gold['loss_in'][1]).cuda()
+    gam, w = torch.tensor([0.3, 0.6]).cuda(), torch.tensor([1.5, 0.7]).cuda()
+    assert np.allclose([float(CustomBCELoss()(pred, gt, gam, w)), float(CustomBCELoss()(pred, gt, gam))], gold['loss_plain'], rtol=1e-5)
+    assert np.allclose([float(CustomBCELoss(brock=True)(pred, gt, gam, w)), float(CustomBCELoss(gamma=0.25)(pred, gt, gam, w))],
+                       gold['loss_brock'], rtol=1e-5)

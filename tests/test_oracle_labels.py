@@ -1,0 +1,45 @@
+"""Supervised forward of the oracle against the fixture generated from the imported reference
+(`tests/golden/make_golden_labels.py`)."""
+import os
+
+import numpy as np
+import torch
+
+from helpers import calib_tensor, golden_nets, seeded_features
+from oracle import pifu_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'labels_small.npz')
+
+
+def _inputs(gold):
+    seed, n = [int(v) for v in gold['seed']]
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(1, 3, n, generator=g) * 2.3 - 1.15
+    labels = (torch.rand(1, 1, n, generator=g) > 0.5).float()
+    return g, pts, labels
+
+
+def test_supervised_query_matches_reference():
+    gold = np.load(GOLD)
+    _, pts, labels = _inputs(gold)
+    sd, oc, of = golden_nets()
+    nets = O.OracleNets(sd, oc, of)
+    nets.feat_coarse, nets.feat_fine = seeded_features(3)
+    with torch.no_grad():
+        r = nets.query_supervised(pts, calib_tensor(), labels)
+    assert np.array_equal(r['labels'].numpy(), gold['labels'])
+    assert np.array_equal(r['coarse_labels'].numpy(), gold['coarse_labels'])
+    assert np.allclose(r['w'].numpy(), gold['w'], rtol=1e-6) and np.allclose(r['gamma'].numpy(), gold['gamma'], rtol=1e-6)
+    assert np.abs(r['preds'].numpy() - gold['preds']).max() < 1e-5
+    assert np.abs(r['preds_low'].numpy() - gold['preds_low']).max() < 1e-5
+    assert abs(float(r['err_fine']) - float(gold['err_fine'][0])) < 1e-5
+
+
+def test_custom_bce_loss_matches_reference():
+    gold = np.load(GOLD)
+    pred, gt = torch.from_numpy(gold['loss_in'][0]), torch.from_numpy(gold['loss_in'][1])
+    gam, w = torch.tensor([0.3, 0.6]), torch.tensor([1.5, 0.7])
+    got = [float(O.custom_bce_loss(pred, gt, gam, w)), float(O.custom_bce_loss(pred, gt, gam))]
+    assert np.allclose(got, gold['loss_plain'], rtol=1e-6)
+    got = [float(O.custom_bce_loss(pred, gt, gam, w, brock=True)), float(O.custom_bce_loss(pred, gt, gam, w, fixed_gamma=0.25))]
+    assert np.allclose(got, gold['loss_brock'], rtol=1e-6)
