@@ -50,9 +50,12 @@ enum {
     PIFU_Q_NO_FINE_MASK = 2,               /* calc_normal: fine prediction not masked (PIFuMRNet.py:223-230) */
     PIFU_Q_FULL_COARSE = 4,                /* run the coarse MLP to its last layer even if pred_coarse is NULL (the
                                               reference always does: netG.query inside PIFuMRNet.query) */
-    PIFU_Q_NO_COLUMN_SHARING = 8           /* lattice sources: evaluate every point independently instead of sharing the
+    PIFU_Q_NO_COLUMN_SHARING = 8,          /* lattice sources: evaluate every point independently instead of sharing the
                                               image-feature products of an (i, j) column (same result up to fp32
                                               summation order; 26 % more FLOPs) */
+    PIFU_Q_NO_DEPTH_WALK = 16              /* lattice sources: evaluate coarse layer 1 as a per-point GEMM instead of
+                                              walking each column along z (layer-0 activations are piecewise linear
+                                              in z inside a column; same result up to fp32 rounding) */
 };
 
 const char *pifu_last_error(void);

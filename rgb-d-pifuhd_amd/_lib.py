@@ -14,7 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
-Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING = 1, 2, 4, 8
+Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
 
 
 class PifuError(RuntimeError):

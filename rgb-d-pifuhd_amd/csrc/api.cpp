@@ -67,6 +67,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
     }
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
     if (const char *v = getenv("PIFU_COLUMN_MODE")) c->col_enable = atoi(v);
+    if (const char *v = getenv("PIFU_DEPTH_WALK")) c->walk_enable = atoi(v);
     if (const char *v = getenv("PIFU_PRECISION")) c->precision = atoi(v);
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;

@@ -56,6 +56,7 @@ struct MlpLayer {
     // column sharing (lattice sources): weights without the skip input's per-column part
     std::vector<float> host_w;   // [cout][cin] as given
     float *w_col = nullptr;      // device [cout_pad | 1][kpad_col]
+    float *w_colT = nullptr;     // device [kpad_col][cout_pad]: transposed copy for the depth walk (coarse layer 1)
     int kpad_col = 0, cin_col = 0;
     float *wz = nullptr;         // device [cout_pad]: weight of the depth feature (coarse level)
     float host_wz0 = 0.f;
@@ -109,6 +110,7 @@ struct pifu_ctx {
     // column tables of the lattice evaluation (column sharing)
     DevBuf col_arena;
     int col_enable = 1;
+    int walk_enable = 1;                  // depth walk of coarse layer 1 on lattice sources (env PIFU_DEPTH_WALK)
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs

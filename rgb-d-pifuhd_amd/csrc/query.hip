@@ -839,7 +839,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
 // One wave per (chunk, group); double accumulation in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int groups, const float *gamma,
-                                const float *beta, float *scale, float *shift, ChunkGeom g, float eps, int halves)
+                                const float *beta, float *scale, float *shift, ChunkGeom g, float eps, int halves,
+                                const int *chunk_row0 = nullptr)
 {
     // one 256-thread block per (chunk, group): a 200 000-point calc_normal chunk has 1 563 tiles x 32 channels per group,
     // too many partials for a single wave.  Fixed summation order (strided per thread, then a fixed LDS tree).
@@ -848,12 +849,14 @@ __global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int grou
     if (wid >= g.nchunks * groups) return;
     const int c = wid / groups, grp = wid % groups;
     const int len = chunk_len(g, c);
-    const int ntile = (len + BM - 1) / BM;
+    // partial rows of this chunk: its 128-row tiles, or (depth walk) its column segments [chunk_row0[c], chunk_row0[c+1])
+    const int prow0 = chunk_row0 ? chunk_row0[c] : c * g.tpc * halves;
+    const int ntile = chunk_row0 ? chunk_row0[c + 1] - chunk_row0[c] : ((len + BM - 1) / BM) * halves;
     double s = 0.0, q = 0.0;
-    const int total = ntile * halves * cpg;       // `halves` partial rows per 128-row tile (2 for k_mlp_gemm_ws)
+    const int total = ntile * cpg;       // (`halves` partial rows per 128-row tile: 2 for k_mlp_gemm_ws)
     for (int i = threadIdx.x; i < total; i += 256) {
         const int t = i / cpg, ch = grp * cpg + i % cpg;
-        const float2 p = partial[(size_t)(c * g.tpc * halves + t) * ld + ch];
+        const float2 p = partial[(size_t)(prow0 + t) * ld + ch];
         s += (double)p.x;
         q += (double)p.y;
     }
@@ -1125,7 +1128,7 @@ __global__ void k_expand(const float *Q, int ldq, const float *wz, const float *
         float4 o;
         o.x = fmaf(w.x, z, v.x) + b.x; o.y = fmaf(w.y, z, v.y) + b.y;
         o.z = fmaf(w.z, z, v.z) + b.z; o.w = fmaf(w.w, z, v.w) + b.w;
-        *reinterpret_cast<float4 *>(Y + row * ldy + ch) = o;
+        if (Y) *reinterpret_cast<float4 *>(Y + row * ldy + ch) = o;      // null: statistics only (depth walk)
         if (r < nvalid) {
             s[0] += o.x; q[0] = fmaf(o.x, o.x, q[0]); s[1] += o.y; q[1] = fmaf(o.y, o.y, q[1]);
             s[2] += o.z; q[2] = fmaf(o.z, o.z, q[2]); s[3] += o.w; q[3] = fmaf(o.w, o.w, q[3]);
@@ -1221,7 +1224,17 @@ struct Carver {
     }
 };
 
+struct WalkPlan {      // depth-walk workspace of one batch (walk.inc); all null when the walk is not available
+    int *tile_cnt = nullptr, *tile_off = nullptr, *seg_row0 = nullptr, *chunk_seg0 = nullptr, *nseg_dev = nullptr, *nflips = nullptr;
+    float *V = nullptr, *PR0 = nullptr;
+    uint32_t *flip_key = nullptr;
+    float2 *flip_d = nullptr, *partial_seg = nullptr;
+    int64_t maxseg = 0;
+    int ntiles = 0;
+};
+
 struct Plan {
+    WalkPlan wk;
     float *featc; int ldc;
     float *finef; int ldf;
     uint8_t *mask;
@@ -1233,10 +1246,28 @@ struct Plan {
     size_t bytes;
 };
 
-Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fine, int64_t normal_pts)
+Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fine, int64_t normal_pts, bool walk = false)
 {
     Plan p;
     Carver c{base};
+    if (walk) {
+        const Mlp &m0 = ctx->mlp[0];
+        const int C0 = m0.layer[0].cout_pad, N1 = m0.layer[1].cout_pad;
+        WalkPlan &w = p.wk;
+        w.maxseg = round_up(rows / 8 > 128 ? rows / 8 : 128, BM);
+        w.ntiles = (int)((rows + 2047) / 2048);
+        w.tile_cnt = c.take<int>(w.ntiles);
+        w.tile_off = c.take<int>(w.ntiles + 1);
+        w.seg_row0 = c.take<int>(w.maxseg + 1);
+        w.chunk_seg0 = c.take<int>(max_chunks + 1);
+        w.nseg_dev = c.take<int>(4);
+        w.nflips = c.take<int>(w.maxseg);
+        w.V = c.take<float>((size_t)2 * w.maxseg * C0);
+        w.PR0 = c.take<float>((size_t)2 * w.maxseg * N1);
+        w.flip_key = c.take<uint32_t>((size_t)w.maxseg * C0);
+        w.flip_d = c.take<float2>((size_t)w.maxseg * C0);
+        w.partial_seg = c.take<float2>((size_t)w.maxseg * N1);
+    }
     const Mlp &mc = ctx->mlp[0];
     p.ldc = (int)round_up(mc.dims[0], BK);
     p.featc = c.take<float>((size_t)rows * p.ldc);
@@ -1476,6 +1507,8 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
     return PIFU_OK;
 }
 
+#include "walk.inc"
+
 // ------------------------------------------------------------------------------------------------
 // Column sharing (lattice sources).  A lattice point (i, j, k) projects to image coordinates that depend on
 // (i, j) only (reconstruction() feeds calib^-1 * grid back through calib), so the sampled image features - 256
@@ -1540,6 +1573,14 @@ static int build_column_weights(pifu_ctx *ctx, int L)
     }
     int rc = upload_vec(&m.colW, cw);
     if (rc) return rc;
+    if (L == 0 && m.nlayers >= 3 && !m.layer[1].cin_feat && m.layer[1].w_col) {      // depth walk: W1^T [C0][N1]
+        MlpLayer &l1 = m.layer[1];
+        if (l1.w_colT) { PIFU_HIP(hipFree(l1.w_colT)); l1.w_colT = nullptr; }
+        PIFU_HIP(hipMalloc(&l1.w_colT, (size_t)l1.cout_pad * l1.kpad_col * sizeof(float)));
+        hipLaunchKernelGGL(k_transpose, dim3((l1.kpad_col + 31) / 32, (l1.cout_pad + 31) / 32), dim3(256), 0, 0,
+                           (const float *)l1.w_col, l1.cout_pad, l1.kpad_col, l1.w_colT);
+        PIFU_HIP(hipDeviceSynchronize());
+    }
     m.col_built = true;
     return PIFU_OK;
 }
@@ -1680,8 +1721,9 @@ static int build_column_tables(pifu_ctx *ctx, bool fine, const SampleArgs &proto
 }
 
 static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTables &T, const ChunkGeom &g, int64_t rows,
-                            int mask_bit, float *pred_out, int upto_layer, hipStream_t st)
+                            int mask_bit, float *pred_out, int upto_layer, hipStream_t st, int walk_nseg = 0)
 {
+    const bool walk = L == 0 && walk_nseg > 0;      // coarse layer 1 by the depth walk (walk.inc)
     const Mlp &m = ctx->mlp[L];
     const LevelBufs &b = pl.lv[L];
     const Mlp &mc = ctx->mlp[0];
@@ -1699,9 +1741,46 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
         PIFU_REQUIRE(ksum == l.kpad_col, PIFU_ERR_STATE, "internal: column-mode K mismatch at level %d layer %d (%d vs %d)", L, i, ksum, l.kpad_col);
         if (i < m.nlayers - 1) {
             if (ns == 0) {   // coarse layer 0: no per-point product left
+                // with the depth walk nobody reads this layer's output: statistics only
                 hipLaunchKernelGGL(k_expand, dim3(ntm, l.cout_pad / 128), dim3(256), 0, st, (const float *)T.Q[L], T.ldq[L],
                                    (const float *)l.wz, (const float *)l.bias, (const float *)pl.zf, (const int *)pl.colidx,
-                                   b.out[i], l.cout_pad, stats ? b.partial[i] : nullptr, g);
+                                   (walk && stats) ? (float *)nullptr : b.out[i], l.cout_pad, stats ? b.partial[i] : nullptr, g);
+            } else if (walk && i == 1) {
+                const MlpLayer &l0 = m.layer[0];
+                const WalkPlan &w = pl.wk;
+                const int C0 = l0.cout_pad, N1 = l.cout_pad;
+                const int nseg = walk_nseg, nseg_pad = (int)round_up(nseg, BM);
+                const Seg prev = make_prev_seg(ctx, m, b, 0);
+                PrepArgs pa{};
+                pa.Q = T.Q[0] + (l0.col_off > 0 ? l0.col_off : 0); pa.ldq = T.ldq[0];
+                pa.wz = l0.wz; pa.bias0 = l0.bias; pa.scale = prev.scale; pa.shift = prev.shift; pa.sld = prev.sld;
+                pa.zf = pl.zf; pa.colidx = pl.colidx; pa.seg_row0 = w.seg_row0; pa.nseg = nseg; pa.nseg_pad = nseg_pad;
+                pa.g = g; pa.C0 = C0; pa.V = w.V; pa.flip_key = w.flip_key; pa.flip_d = w.flip_d; pa.nflips = w.nflips;
+                hipLaunchKernelGGL(k_seg_prepare, dim3(nseg), dim3(256), 0, st, pa);
+                GemmArgs a{};       // start values (P, R) of every segment: [m alpha ; m beta] * W1^T
+                a.seg[0] = Seg{w.V, ctx->ident_scale, ctx->ident_shift, C0, C0, 0, 0};
+                a.nseg = 1;
+                a.W = l.w_col; a.ldw = l.kpad_col; a.bias = ctx->ident_shift;
+                a.Y = w.PR0; a.ldy = N1; a.partial = nullptr;
+                a.ntm = 2 * nseg_pad / BM; a.ntn = N1 / BN;
+                a.g.tpc = a.ntm; a.g.chunk = 2 * nseg_pad; a.g.last_len = 2 * nseg_pad; a.g.nchunks = 1;
+                int rc = run_gemm(ctx, a, 2.0 * 2.0 * nseg * (double)l.cout * (double)l.cin_col, st);
+                if (rc) return rc;
+                WalkArgs wa{};
+                wa.PR0 = w.PR0; wa.nseg_pad = nseg_pad; wa.W1T = l.w_colT; wa.bias1 = l.bias;
+                wa.flip_key = w.flip_key; wa.flip_d = w.flip_d; wa.nflips = w.nflips;
+                wa.zf = pl.zf; wa.seg_row0 = w.seg_row0; wa.nseg = nseg; wa.g = g; wa.C0 = C0; wa.N1 = N1;
+                wa.Y = b.out[i]; wa.ldy = l.cout_pad; wa.partial_seg = stats ? w.partial_seg : nullptr;
+                if (N1 == 256) hipLaunchKernelGGL(k_walk<1>, dim3(nseg), dim3(256), 0, st, wa);
+                else if (N1 == 512) hipLaunchKernelGGL(k_walk<2>, dim3(nseg), dim3(256), 0, st, wa);
+                else hipLaunchKernelGGL(k_walk<4>, dim3(nseg), dim3(256), 0, st, wa);
+                if (stats) {
+                    const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
+                    hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.partial_seg,
+                                       l.cout_pad, l.cout / groups, groups, (const float *)l.gamma, (const float *)l.beta,
+                                       b.scale[i], b.shift[i], g, 1e-5f, 1, (const int *)w.chunk_seg0);
+                }
+                continue;
             } else {
                 GemmArgs a{};
                 for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
@@ -1781,10 +1860,25 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     if (batch_chunks > total_chunks) batch_chunks = total_chunks;
     const int64_t rows_cap = batch_chunks * P;
     const int64_t normal_pts = src_mode == 3 ? n : 0;
-    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts);
+    // column sharing applies when the projected (x, y) of a lattice point does not depend on k
+    bool colmode = (src_mode == 1 || src_mode == 2) && ctx->col_enable && !(flags & PIFU_Q_NO_COLUMN_SHARING) &&
+                   ctx->mlp[0].nlayers >= 2 && !ctx->mlp[0].res[0];
+    if (colmode)
+        colmode = calib[2] == 0.f && calib[6] == 0.f && calib_inv[2] == 0.0 && calib_inv[6] == 0.0 &&
+                  (int64_t)res[0] * res[1] < ((int64_t)1 << 31);
+    // depth walk of coarse layer 1 (walk.inc): layer 1 must take the activated layer-0 output only
+    bool walk_ok = false;
+    if (colmode && ctx->walk_enable && !(flags & PIFU_Q_NO_DEPTH_WALK)) {
+        const Mlp &m0 = ctx->mlp[0];
+        const int C0 = m0.layer[0].cout_pad, N1 = m0.nlayers >= 3 ? m0.layer[1].cout_pad : 0;
+        walk_ok = m0.nlayers >= 3 && !m0.res[1] && m0.layer[0].has_norm && C0 <= 1024 && C0 % 256 == 0 &&
+                  (N1 == 256 || N1 == 512 || N1 == 1024) && res[2] < 65536 && (mc.merge_layer >= 1 || !fine) &&
+                  rows_cap * 4 < ((int64_t)1 << 31);
+    }
+    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok);
     int rc = pifu_ensure(ctx->arena, probe.bytes);
     if (rc != PIFU_OK) return rc;
-    Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts);
+    Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts, walk_ok);
 
     float *fine_out = pred_fine;
     if (src_mode == 3) {   // calc_normal consumes the predictions itself
@@ -1793,12 +1887,6 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     }
     if ((flags & PIFU_Q_FULL_COARSE) && !pred_coarse) pred_coarse = pl.coarse_scratch;
 
-    // column sharing applies when the projected (x, y) of a lattice point does not depend on k
-    bool colmode = (src_mode == 1 || src_mode == 2) && ctx->col_enable && !(flags & PIFU_Q_NO_COLUMN_SHARING) &&
-                   ctx->mlp[0].nlayers >= 2 && !ctx->mlp[0].res[0];
-    if (colmode)
-        colmode = calib[2] == 0.f && calib[6] == 0.f && calib_inv[2] == 0.0 && calib_inv[6] == 0.0 &&
-                  (int64_t)res[0] * res[1] < ((int64_t)1 << 31);
     ColTables T;
     bool tables_ready = false;
 
@@ -1841,7 +1929,33 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                 tables_ready = true;
             }
             hipLaunchKernelGGL(k_sample_col, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sa, pl.zf, pl.colidx, T.col_base);
-            rc = launch_level_col(ctx, 0, pl, T, g, rows, 1, coarse_dst, upto, st);
+            int walk_nseg = 0;
+            if (walk_ok && ctx->mlp[0].layer[1].w_colT && upto >= 2) {
+                // column segments of this batch (ordered compaction of the segment starts)
+                const WalkPlan &w = pl.wk;
+                const int ntiles = (int)((rows + SEG_TILE - 1) / SEG_TILE);
+                hipLaunchKernelGGL(k_seg_count, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, g, rows, w.tile_cnt);
+                hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int *)w.tile_cnt, ntiles, w.tile_off, w.nseg_dev,
+                                   w.chunk_seg0, g.nchunks);
+                hipLaunchKernelGGL(k_seg_scatter, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, g, rows,
+                                   (const int *)w.tile_off, w.seg_row0, w.chunk_seg0, w.maxseg);
+                int64_t nseg = 0;
+                if (src_mode == 1) {        // dense range: the count is known on the host
+                    for (int64_t c = 0; c < nc; ++c) {
+                        const int64_t i0 = first + pt0 + c * chunk;
+                        const int64_t len = c == nc - 1 ? g.last_len : chunk;
+                        nseg += (i0 + len - 1) / res[2] - i0 / res[2] + 1;
+                    }
+                } else {
+                    int host_n = 0;
+                    PIFU_HIP(hipMemcpyAsync(&host_n, w.nseg_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+                    PIFU_HIP(hipStreamSynchronize(st));
+                    nseg = host_n;
+                }
+                // worth it only for segments of some length (start values cost 2 C0 N1 MACs per segment)
+                if (nseg > 0 && nseg <= w.maxseg && nseg * 8 <= npts) walk_nseg = (int)nseg;
+            }
+            rc = launch_level_col(ctx, 0, pl, T, g, rows, 1, coarse_dst, upto, st, walk_nseg);
             if (rc != PIFU_OK) return rc;
             if (fine) {
                 rc = launch_level_col(ctx, 1, pl, T, g, rows, (flags & PIFU_Q_NO_FINE_MASK) ? 0 : 2,
