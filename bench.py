@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
                     help="feature maps from the real encoders (filter) or seeded random maps of the same shape")
     ap.add_argument('--lean', action='store_true', help='skip the coarse MLP layers whose output nobody reads')
+    ap.add_argument('--no-depth-walk', action='store_true',
+                    help='evaluate coarse layer 1 as a per-point GEMM instead of walking the columns along z')
     ap.add_argument('--no-column-sharing', action='store_true',
                     help='evaluate every lattice point independently (the canonical 2 916 098 FLOP per query)')
     args = ap.parse_args()
@@ -162,6 +164,8 @@ def main():
     flags = 0 if args.lean else _lib.Q_FULL_COARSE
     if args.no_column_sharing:
         flags |= _lib.Q_NO_COLUMN_SHARING
+    if args.no_depth_walk:
+        flags |= _lib.Q_NO_DEPTH_WALK
     h = netMR._ctx.h
     _lib.call('pifu_reserve', h, 262144)
 
@@ -227,6 +231,7 @@ def main():
                         f'1024px RGB image + 512px, name-seeded weights',
             'queries_per_step': total, 'chunk': args.chunk, 'coarse_tail': 'skipped' if args.lean else 'computed',
             'column_sharing': not args.no_column_sharing,
+            'depth_walk': not (args.no_depth_walk or args.no_column_sharing),
             'flop_per_query_canonical': FLOP_PER_QUERY,
             # what the GEMM launches of the timed region actually executed (column sharing removes the per-point
             # image-feature products: 2 163 200 FLOP per query + the per-column tables)

@@ -187,3 +187,52 @@ def test_column_sharing_equals_per_point_evaluation():
     a = run(0, idx, 0, 12345)
     b = run(_lib.Q_NO_COLUMN_SHARING, idx, 0, 12345)
     assert np.abs(a - b).max() < 2e-5
+
+
+@pytest.mark.parametrize('mlp_norm', ['group', 'batch', 'no'])
+def test_depth_walk_equals_gemm_paths(mlp_norm):
+    """Coarse layer 1 by the depth walk (walk.inc) vs the same layer as a GEMM (Q_NO_DEPTH_WALK) vs the canonical
+    per-point evaluation: dense ranges whose chunks cut columns, an octree-like shell (index list with long column
+    segments, which takes the device-count path), and the coarse-only net."""
+    import ctypes as C
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = golden_nets(mlp_norm=mlp_norm)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(5)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = np.ascontiguousarray(calib_tensor()[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    R0, R1, R2 = 20, 24, 56
+    res = (C.c_int32 * 3)(R0, R1, R2)
+    tol = 2e-5 if mlp_norm == 'group' else 1e-4
+
+    def run(flags, index, first, count, chunk=700):
+        out = torch.empty(count, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  _ptr(index), first, count, chunk, flags, _ptr(out), _stream_ptr(netMR.device))
+        return out.cpu().numpy()
+    total = R0 * R1 * R2
+    for first, count in ((0, total), (700 * 3 + 0, 700 * 5 + 333)):
+        w = run(_lib.Q_FULL_COARSE, None, first, count)
+        g = run(_lib.Q_FULL_COARSE | _lib.Q_NO_DEPTH_WALK, None, first, count)
+        p = run(_lib.Q_FULL_COARSE | _lib.Q_NO_COLUMN_SHARING, None, first, count)
+        assert np.abs(w - g).max() < tol and np.abs(w - p).max() < tol
+        assert np.abs(w - g).max() > 0                       # really a different computation
+        assert np.array_equal(w, run(_lib.Q_FULL_COARSE, None, first, count))      # reproducible
+    # shell: every column, k in [9, 41) -> 32-point segments; chunk 5000 cuts them
+    k = torch.arange(9, 41)
+    idx = (torch.arange(R0 * R1)[:, None] * R2 + k[None, :]).reshape(-1).cuda()
+    w = run(0, idx, 0, idx.numel(), 5000)
+    g = run(_lib.Q_NO_DEPTH_WALK, idx, 0, idx.numel(), 5000)
+    p = run(_lib.Q_NO_COLUMN_SHARING, idx, 0, idx.numel(), 5000)
+    assert np.abs(w - g).max() < tol and np.abs(w - p).max() < tol and np.abs(w - g).max() > 0
+    # scattered points (segments of length ~1): the walk declines, the result is the GEMM path's bit for bit
+    gsel = torch.Generator().manual_seed(5)
+    sidx = torch.sort(torch.randperm(total, generator=gsel)[:3000])[0].cuda()
+    assert np.array_equal(run(0, sidx, 0, 3000, 5000), run(_lib.Q_NO_DEPTH_WALK, sidx, 0, 3000, 5000))
+    # coarse-only net
+    w = run(_lib.Q_COARSE_ONLY, None, 0, total)
+    p = run(_lib.Q_COARSE_ONLY | _lib.Q_NO_COLUMN_SHARING, None, 0, total)
+    assert np.abs(w - p).max() < tol
