@@ -184,6 +184,12 @@ def main():
     log('warm-up done')
     _lib.call('pifu_profile_read', h, None, None, None, 1)
     _lib.call('pifu_profile_enable', h, 1)
+
+    def clock_probe():
+        buf = (C.c_uint64 * 16)()
+        _lib.call('pifu_clock_probe', h, buf, _stream_ptr(dev))
+        return list(buf)
+    clk0 = clock_probe()            # per-XCD (shader ticks, 100 MHz real-time ticks) just outside the timed region
     fence()
     t0 = time.perf_counter()
     field = None
@@ -191,7 +197,13 @@ def main():
         field = step()
     fence()
     elapsed = time.perf_counter() - t0
+    clk1 = clock_probe()
     log(f'timed region done: {elapsed:.3f} s')
+    # average shader clock over the timed region: shader-counter ticks per real-time tick (100 MHz), per XCD that
+    # both probes sampled; s_memtime counts the clock the CUs actually ran at (power management included)
+    mhz = [100.0 * (clk1[2 * x] - clk0[2 * x]) / (clk1[2 * x + 1] - clk0[2 * x + 1])
+           for x in range(8) if clk0[2 * x + 1] and clk1[2 * x + 1] > clk0[2 * x + 1]]
+    eff_mhz = sum(mhz) / len(mhz) if mhz else None
     _lib.call('pifu_profile_enable', h, 0)
     gemm_ms, gemm_n, gemm_flops = C.c_double(0), C.c_int64(0), C.c_double(0)
     _lib.call('pifu_profile_read', h, C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_flops), 1)
@@ -245,6 +257,9 @@ def main():
             'launches': gemm_n.value, 'avg_launch_ms': round(gemm_ms.value / max(gemm_n.value, 1), 4),
             'alg_gflop_per_launch': round(gemm_flops.value / max(gemm_n.value, 1) / 1e9, 3),
             'gemm_time_share_of_step': round(gemm_ms.value * 1e-3 / elapsed, 4),
+            # measured beside the nominal-clock figures above: the peak assumes 2 400 MHz, the fp32-MFMA load runs lower
+            'shader_clock_mhz_measured': round(eff_mhz, 1) if eff_mhz else None,
+            'frac_at_measured_clock': round(achieved / (PEAK_FP32_MATRIX_TFLOPS * eff_mhz / 2400.0), 4) if eff_mhz else None,
         },
     }
 

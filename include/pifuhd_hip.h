@@ -190,6 +190,12 @@ int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const
 int pifu_profile_enable(pifu_ctx *ctx, int on);
 int pifu_profile_read(pifu_ctx *ctx, double *gemm_ms, int64_t *gemm_launches, double *gemm_flops, int reset);
 
+/* pifu_clock_probe synchronises the stream and returns, per XCD (8 on MI355X), the shader-clock counter (s_memtime)
+ * and the constant 100 MHz real-time counter (s_memrealtime) read by one wave on that XCD: out[2 * xcd] = shader ticks,
+ * out[2 * xcd + 1] = real-time ticks (0, 0 for an XCD no probe wave landed on).  Two probes around a timed region give
+ * the AVERAGE shader clock the region actually ran at (bench.py reports it beside the nominal-clock roofline). */
+int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream stream);
+
 /* ---- OBJ writer: save_obj_mesh_with_color (mesh_util.py:189-198); host buffers ------------------ */
 int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                    const int32_t *faces, int64_t nfaces);

@@ -61,6 +61,7 @@ SIGNATURES = {
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
     'pifu_profile_enable': (_i32, [_p, _i32]),
     'pifu_profile_read': (_i32, [_p, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
+    'pifu_clock_probe': (_i32, [_p, _p, _p]),
     'pifu_write_obj': (_i32, [C.c_char_p, _p, _p, _i64, _p, _i64]),
 }
 

@@ -1360,7 +1360,11 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     }
     GemmArgs b = a;
     if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
-    if (ctx->gemm_variant == 6) {
+    if (ctx->gemm_variant == 20) {      // persistent blocks with cross-tile prefetch (rejected: same speed, see gemm_experiments.inc)
+        const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
+        b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
+        hipLaunchKernelGGL(k_mlp_gemm_pers, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
+    } else if (ctx->gemm_variant == 6) {
         b.stamps = (ctx->debug_buf && a.ldw == 1024) ? (unsigned long long *)ctx->debug_buf : nullptr;   // coarse L1 only
         hipLaunchKernelGGL(k_mlp_gemm_buf2, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
     } else if (ctx->gemm_variant == 4)
@@ -1599,8 +1603,9 @@ static int prof_begin(pifu_ctx *ctx, hipStream_t st, hipEvent_t *e1)
     if (!ctx->prof_on) return PIFU_OK;
     if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
         hipEvent_t a0, a1;
-        PIFU_HIP(hipEventCreate(&a0));
-        PIFU_HIP(hipEventCreate(&a1));
+        // device-scope release only: a system-scope fence per event costs ~5 us of idle GPU around every timed launch
+        PIFU_HIP(hipEventCreateWithFlags(&a0, hipEventDisableSystemFence));
+        PIFU_HIP(hipEventCreateWithFlags(&a1, hipEventDisableSystemFence));
         ctx->prof_ev.push_back(a0);
         ctx->prof_ev.push_back(a1);
     }
@@ -1740,7 +1745,19 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
         for (int s = 0; s < ns; ++s) ksum += segs[s].width;
         PIFU_REQUIRE(ksum == l.kpad_col, PIFU_ERR_STATE, "internal: column-mode K mismatch at level %d layer %d (%d vs %d)", L, i, ksum, l.kpad_col);
         if (i < m.nlayers - 1) {
-            if (ns == 0) {   // coarse layer 0: no per-point product left
+            if (ns == 0 && walk && stats) {
+                // coarse layer 0 under the depth walk: nobody reads its output, and its statistics have a closed form per
+                // column segment (flip_d is free until k_seg_prepare, which runs after this layer's k_norm_finalize)
+                const WalkPlan &w = pl.wk;
+                hipLaunchKernelGGL(k_seg_stats0, dim3(walk_nseg), dim3(256), 0, st, (const float *)T.Q[L] + (l.col_off > 0 ? l.col_off : 0),
+                                   T.ldq[L], (const float *)l.wz, (const float *)l.bias, (const float *)pl.zf, (const int *)pl.colidx,
+                                   (const int *)w.seg_row0, walk_nseg, g, l.cout_pad, w.flip_d);
+                const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
+                hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.flip_d,
+                                   l.cout_pad, l.cout / groups, groups, (const float *)l.gamma, (const float *)l.beta,
+                                   b.scale[i], b.shift[i], g, 1e-5f, 1, (const int *)w.chunk_seg0);
+                continue;
+            } else if (ns == 0) {   // coarse layer 0: no per-point product left
                 // with the depth walk nobody reads this layer's output: statistics only
                 hipLaunchKernelGGL(k_expand, dim3(ntm, l.cout_pad / 128), dim3(256), 0, st, (const float *)T.Q[L], T.ldq[L],
                                    (const float *)l.wz, (const float *)l.bias, (const float *)pl.zf, (const int *)pl.colidx,
@@ -1771,9 +1788,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 wa.flip_key = w.flip_key; wa.flip_d = w.flip_d; wa.nflips = w.nflips;
                 wa.zf = pl.zf; wa.seg_row0 = w.seg_row0; wa.nseg = nseg; wa.g = g; wa.C0 = C0; wa.N1 = N1;
                 wa.Y = b.out[i]; wa.ldy = l.cout_pad; wa.partial_seg = stats ? w.partial_seg : nullptr;
-                if (N1 == 256) hipLaunchKernelGGL(k_walk<1>, dim3(nseg), dim3(256), 0, st, wa);
-                else if (N1 == 512) hipLaunchKernelGGL(k_walk<2>, dim3(nseg), dim3(256), 0, st, wa);
-                else hipLaunchKernelGGL(k_walk<4>, dim3(nseg), dim3(256), 0, st, wa);
+                hipLaunchKernelGGL(k_walk<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
                 if (stats) {
                     const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                     hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.partial_seg,
@@ -2032,6 +2047,31 @@ int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64
     hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)pred4, n, normals);
     PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+namespace {
+// one wave per block; the first wave to arrive on an XCD records that XCD's counters
+__global__ void k_clock_probe(unsigned long long *out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 7u;       // HW_REG_XCC_ID
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    if (atomicCAS(out + 2 * xcc + 1, 0ull, r) == 0ull) out[2 * xcc] = t;
+}
+}  // namespace
+
+extern "C" int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && out, PIFU_ERR_INVALID, "pifu_clock_probe: null argument");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->clock_buf) PIFU_HIP(hipMalloc(&ctx->clock_buf, 16 * sizeof(unsigned long long)));
+    PIFU_HIP(hipMemsetAsync(ctx->clock_buf, 0, 16 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_clock_probe, dim3(64), dim3(64), 0, st, (unsigned long long *)ctx->clock_buf);
+    PIFU_HIP(hipGetLastError());
+    PIFU_HIP(hipMemcpyAsync(out, ctx->clock_buf, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PIFU_HIP(hipStreamSynchronize(st));
     return PIFU_OK;
 }
 
