@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--res', type=int, default=256, help='lattice points per axis per GPU slab')
     ap.add_argument('--chunk', type=int, default=5000)
+    ap.add_argument('--batch-rows', type=int, default=2097152, help='point rows evaluated per batch of launches (workspace ~12.5 KB per row: 26 GB at the default)')
     ap.add_argument('--cpu-chunks', type=int, default=200, help='chunks of the workload timed on the CPU oracle')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time bound of the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=32)
@@ -167,7 +168,7 @@ def main():
     if args.no_depth_walk:
         flags |= _lib.Q_NO_DEPTH_WALK
     h = netMR._ctx.h
-    _lib.call('pifu_reserve', h, 262144)
+    _lib.call('pifu_reserve', h, args.batch_rows)
 
     def step():
         return pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, flags)
@@ -241,7 +242,7 @@ def main():
             'workload': f'dense {res[0]}x{res[1]}x{res[2]} lattice ({R}^3 per GPU, axis-0 chunk-range slabs, RCCL '
                         f'all-gather of the fp32 field), coarse+fine PIFuMRNet query, chunk {args.chunk}, '
                         f'1024px RGB image + 512px, name-seeded weights',
-            'queries_per_step': total, 'chunk': args.chunk, 'coarse_tail': 'skipped' if args.lean else 'computed',
+            'queries_per_step': total, 'chunk': args.chunk, 'batch_rows': args.batch_rows, 'coarse_tail': 'skipped' if args.lean else 'computed',
             'column_sharing': not args.no_column_sharing,
             'depth_walk': not (args.no_depth_walk or args.no_column_sharing),
             'flop_per_query_canonical': FLOP_PER_QUERY,
