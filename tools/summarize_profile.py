@@ -21,7 +21,7 @@ def short(name):
 
 
 # (1) kernel stats
-stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+stats = sorted(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime, reverse=True)
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 '
@@ -33,7 +33,7 @@ with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
 
 def pmc(dirname):
     out = defaultdict(lambda: defaultdict(list))
-    for p in glob.glob(os.path.join(src, dirname, '*', '*_counter_collection.csv')):
+    for p in sorted(glob.glob(os.path.join(src, dirname, '*', '*_counter_collection.csv')), key=os.path.getmtime, reverse=True)[:1]:
         for r in csv.DictReader(open(p)):
             out[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     return out
@@ -53,8 +53,8 @@ for k in (GEMM, 'k_sample_col', 'k_expand', 'k_last_layer'):
 g = sq.get(GEMM, {})
 if g:
     summary[GEMM + '_sq'] = {c: sum(v) / len(v) for c, v in g.items()}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 --res 128 '
-                     '(same per-launch geometry as the headline run: 51 chunks x 5120 rows)',
+json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 (the headline lattice and batch '
+                     'geometry: per-launch averages over the same launch mix as the timed run)',
            'gemm_kernel': GEMM,
            'k_mlp_gemm_hbm_bytes_per_launch': summary.get(GEMM, {}).get('hbm_bytes_per_launch'),
            'detail': summary}, open('profiles/traffic.json', 'w'), indent=1)
