@@ -573,6 +573,196 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_mlp_gemm_wide: the same GEMM on a 128 (points) x 256 (channels) x 16 (K) block tile, for layers whose padded Cout is a
+// multiple of 256.  4 waves, each a 64 x 128 output tile = 2 x 4 MFMA tiles (128 accumulator VGPRs); still 64 MFMAs per
+// wave between two barriers, but an A element (loaded, normalised, activated, written to LDS) now feeds 256 output
+// columns instead of 128, a K step moves 24 KB through LDS staging instead of 32 KB, and 12 instead of 16 fragment
+// reads feed the 64 MFMAs: the non-MFMA work that the fp32 MFMA cannot hide shrinks by about a third.  LDS 61 KB
+// (K step 16, row stride 20 floats) keeps two blocks per CU.  Same k order per accumulator and the same per-128-row
+// statistics partials as k_mlp_gemm_buf: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm_wide(const GemmArgs a)
+{
+    constexpr int TBK = 16, LD = TBK + 4, WN = 256, ATILE = BM * LD, BTILE = WN * LD, STG = ATILE + BTILE, NS = TBK / 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STG];   // [buf][A | B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = a.ntn / 2;                    // 256-column tiles
+    const int q_tile = blockIdx.x;
+    const int xcd = q_tile & 7, slot = q_tile >> 3;
+    const int tile_n = slot % ntn;
+    const int tile_m = (slot / ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM;
+    const int col0 = tile_n * WN;
+
+    const int kq = tid & 3, sr = tid >> 2;        // staging: float4 column kq of rows sr + 64 p
+    const unsigned kb = kq * 16;
+    const int nsteps = a.ldw / TBK;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
+    const unsigned voW = (unsigned)sr * ldw4 + kb;
+
+    float4 ra0, ra1, rw0, rw1, rw2, rw3, rsc, rsh;
+    float rslope = 1.f;
+    int c_seg = 0, c_left = a.seg[0].width / TBK;
+    unsigned c_ks4 = 0, c_kw4 = 0;
+    unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
+    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0 * (size_t)a.seg[0].ld);
+    __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
+    __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
+    float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
+    unsigned voA = (unsigned)sr * c_ld4 + kb;
+#define WIDE_GLOAD()                                                                                       \
+    {                                                                                                      \
+        rslope = c_slope;                                                                                  \
+        ra0 = buf_load4(c_rA, voA, c_ks4);                                                                 \
+        ra1 = buf_load4(c_rA, voA, c_ks4 + 64u * c_ld4);                                                   \
+        rsc = buf_load4(c_rsc, kb, c_ks4);                                                                 \
+        rsh = buf_load4(c_rsh, kb, c_ks4);                                                                 \
+        rw0 = buf_load4(rW, voW, c_kw4);                                                                   \
+        rw1 = buf_load4(rW, voW, c_kw4 + 64u * ldw4);                                                      \
+        rw2 = buf_load4(rW, voW, c_kw4 + 128u * ldw4);                                                     \
+        rw3 = buf_load4(rW, voW, c_kw4 + 192u * ldw4);                                                     \
+        c_ks4 += TBK * 4u;                                                                                 \
+        c_kw4 += TBK * 4u;                                                                                 \
+        if (--c_left == 0 && ++c_seg < a.nseg) {                                                           \
+            const float *np_ = c_seg == 1 ? a.seg[1].ptr : a.seg[2].ptr;                                   \
+            const float *nsc_ = c_seg == 1 ? a.seg[1].scale : a.seg[2].scale;                              \
+            const float *nsh_ = c_seg == 1 ? a.seg[1].shift : a.seg[2].shift;                              \
+            const int nld_ = c_seg == 1 ? a.seg[1].ld : a.seg[2].ld;                                       \
+            const int nsld_ = c_seg == 1 ? a.seg[1].sld : a.seg[2].sld;                                    \
+            const int nmd_ = c_seg == 1 ? a.seg[1].mode : a.seg[2].mode;                                   \
+            c_left = (c_seg == 1 ? a.seg[1].width : a.seg[2].width) / TBK;                                 \
+            c_ks4 = 0;                                                                                     \
+            c_ld4 = (unsigned)nld_ * 4u;                                                                   \
+            c_rA = buf_rsrc(np_ + row0 * (size_t)nld_);                                                    \
+            c_rsc = buf_rsrc(nsc_ + (size_t)chunk_id * nsld_);                                             \
+            c_rsh = buf_rsrc(nsh_ + (size_t)chunk_id * nsld_);                                             \
+            c_slope = nmd_ == 0 ? 1.f : 0.01f;                                                             \
+            voA = (unsigned)sr * c_ld4 + kb;                                                               \
+        }                                                                                                  \
+    }
+#define WIDE_LSTORE(buf_)                                                                                  \
+    {                                                                                                      \
+        float *la = lds + (buf_) * STG + sr * LD + kq * 4;                                                 \
+        BUF_XF(ra0) BUF_XF(ra1)                                                                            \
+        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
+        *reinterpret_cast<float4 *>(la + 64 * LD) = ra1;                                                   \
+        *reinterpret_cast<float4 *>(la + ATILE) = rw0;                                                     \
+        *reinterpret_cast<float4 *>(la + ATILE + 64 * LD) = rw1;                                           \
+        *reinterpret_cast<float4 *>(la + ATILE + 128 * LD) = rw2;                                          \
+        *reinterpret_cast<float4 *>(la + ATILE + 192 * LD) = rw3;                                          \
+    }
+
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    WIDE_GLOAD()
+    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z
+        const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
+        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);
+        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
+        float wz[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wz[nt] = a.colwz ? a.colwz[col0 + wn * 128 + nt * 32 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+            const unsigned ciA = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so, 0);
+            const unsigned ciB = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so + 128u, 0);
+            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
+            const unsigned qA = ciA * ldq4 + (unsigned)(wn * 128 + j) * 4u, qB = ciB * ldq4 + (unsigned)(wn * 128 + j) * 4u;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[0][nt][r] = fmaf(wz[nt], zA, buf_load1(rQ, qA, nt * 128));
+                acc[1][nt][r] = fmaf(wz[nt], zB, buf_load1(rQ, qB, nt * 128));
+            }
+        }
+    }
+    WIDE_LSTORE(0)
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) WIDE_GLOAD()
+        const float *A = lds + buf * STG + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float *B = lds + buf * STG + ATILE + (wn * 128 + (lane & 31)) * LD + (lane >> 5) * 4;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
+            float4 bq[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bq[nt] = *reinterpret_cast<const float4 *>(B + nt * 32 * LD + s * 8);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float bv = t == 0 ? bq[nt].x : (t == 1 ? bq[nt].y : (t == 2 ? bq[nt].z : bq[nt].w));
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv, acc[1][nt], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) WIDE_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = lds;   // [2 (sum|sq)][2 (wm)][WN]; safe: every wave passed the loop's final barrier
+    const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
+    const unsigned ldy4 = (unsigned)a.ldy * 4u;
+    const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 128 + j) * 4u;
+    float sm[4], sq[4];
+    const bool full = nvalid >= BM;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float bias = a.bias[col0 + wn * 128 + nt * 32 + j];
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = mt * 32 + (r & 3) + 8 * (r >> 2);
+                const float v = acc[mt][nt][r] + bias;
+                buf_store1(v, rY, voY, (unsigned)rr * ldy4 + nt * 128u);
+                if (full || wm * 64 + rr + 4 * h < nvalid) { s_ += v; q_ = fmaf(v, v, q_); }
+            }
+        sm[nt] = s_; sq[nt] = q_;
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sm[nt] += __shfl_xor(sm[nt], 32); sq[nt] += __shfl_xor(sq[nt], 32);
+            if (lane < 32) {
+                red[(0 * 2 + wm) * WN + wn * 128 + nt * 32 + j] = sm[nt];
+                red[(1 * 2 + wm) * WN + wn * 128 + nt * 32 + j] = sq[nt];
+            }
+        }
+        __syncthreads();
+        a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+            make_float2(red[tid] + red[WN + tid], red[2 * WN + tid] + red[3 * WN + tid]);
+    }
+#undef WIDE_GLOAD
+#undef WIDE_LSTORE
+}
+
 #ifdef PIFU_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
 #endif
@@ -1374,6 +1564,8 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
 #else
     if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else if (ctx->gemm_variant == 21 && a.ntn % 2 == 0)
+        hipLaunchKernelGGL(k_mlp_gemm_wide, dim3((unsigned)round_up(a.ntm, 8) * (a.ntn / 2)), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(k_mlp_gemm_buf, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 #endif

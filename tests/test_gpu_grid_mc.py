@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import calib_tensor, golden_nets, noisy_field, seeded_features
+from helpers import calib_tensor, golden_nets, mlp_only_nets, noisy_field, seeded_features
 
 pytestmark = pytest.mark.gpu
 
@@ -236,3 +236,75 @@ def test_depth_walk_equals_gemm_paths(mlp_norm):
     w = run(_lib.Q_COARSE_ONLY, None, 0, total)
     p = run(_lib.Q_COARSE_ONLY | _lib.Q_NO_COLUMN_SHARING, None, 0, total)
     assert np.abs(w - p).max() < tol
+
+
+def test_full_size_lattice_properties():
+    """BASELINE configs[1] at full size (dense 256^3, chunk 5000) through size-independent properties: the field does
+    not depend on how many rows go into one batch of launches, a chunk-aligned slab evaluated on its own (the unit the
+    multi-GPU path shards by) is the corresponding slice of the full field bit for bit, reruns are bit-identical, and
+    chunks sampled from the field (first, middle, ragged last) agree with the CPU oracle within the north star's 1e-4."""
+    import ctypes as C
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = mlp_only_nets()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    netMR = nets.PIFuMRNet(of, netG)
+    netG.eval()
+    netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}
+    netG._push_weights()
+    netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}
+    netMR._push_weights()
+    fc, ff = seeded_features(21, hc=128, hf=512)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib_t = calib_tensor()
+    calib = np.ascontiguousarray(calib_t[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    R, chunk = 256, 5000
+    res = (C.c_int32 * 3)(R, R, R)
+    total = R ** 3
+    h = netMR._ctx.h
+
+    def run(first, count, rows):
+        _lib.call('pifu_reserve', h, rows)
+        out = torch.empty(count, device='cuda')
+        _lib.call('pifu_eval_lattice', h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  None, first, count, chunk, _lib.Q_FULL_COARSE, _ptr(out), _stream_ptr(netMR.device))
+        return out
+    full = run(0, total, 2097152)
+    assert torch.equal(full, run(0, total, 2097152))                      # reproducible
+    assert torch.equal(full, run(0, total, 262144))                       # independent of the batch size
+    first, count = 1000 * chunk, 300 * chunk                              # a slab of whole chunks that cuts columns
+    assert torch.equal(full[first:first + count], run(first, count, 1048576))
+    assert float(full.min()) >= 0.0 and float(full.max()) <= 1.0 and float(full.std()) > 1e-3
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    n_chunks = (total + chunk - 1) // chunk
+    with torch.no_grad():
+        for c in (0, n_chunks // 2, n_chunks - 1):
+            lo, hi = c * chunk, min((c + 1) * chunk, total)
+            pts = torch.from_numpy(O.grid_points_rect((R, R, R), cinv, np.arange(lo, hi, dtype=np.int64)).astype(np.float32))[None]
+            want = ref.query(pts, calib_t)[0, 0].numpy()
+            assert np.abs(full[lo:hi].cpu().numpy() - want).max() < 1e-4
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """pifu_clock_probe (bench.py's measured-clock figure): two probes around some work give, per XCD sampled by both,
+    shader ticks per 100 MHz real-time tick in the range the part can run at."""
+    import ctypes as C
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _stream_ptr
+    sd, oc, of = mlp_only_nets()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    h = netG._ctx.h
+    a, b = (C.c_uint64 * 16)(), (C.c_uint64 * 16)()
+    _lib.call('pifu_clock_probe', h, a, _stream_ptr(netG.device))
+    x = torch.randn(4096, 4096, device='cuda')
+    for _ in range(20):
+        x = torch.tanh(x @ x * 1e-3)
+    torch.cuda.synchronize()
+    _lib.call('pifu_clock_probe', h, b, _stream_ptr(netG.device))
+    mhz = [100.0 * (b[2 * i] - a[2 * i]) / (b[2 * i + 1] - a[2 * i + 1]) for i in range(8) if a[2 * i + 1] and b[2 * i + 1] > a[2 * i + 1]]
+    assert mhz, 'no XCD was sampled by both probes'
+    assert all(50.0 < m < 3000.0 for m in mhz), mhz
