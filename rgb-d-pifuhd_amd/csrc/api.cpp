@@ -129,6 +129,7 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
     if (ctx->debug_buf) (void)hipFree(ctx->debug_buf);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);

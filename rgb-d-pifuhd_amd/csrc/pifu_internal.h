@@ -118,6 +118,8 @@ struct pifu_ctx {
     // optional per-launch timing of the dominant kernel (k_mlp_gemm) with HIP events on the launch stream
     int num_cus = 256;
     void *debug_buf = nullptr;            // diagnostics only
+    void *tile_ctr = nullptr;             // k_mlp_gemm_dyn work-queue counters: ring of [8] int slots
+    int tile_ctr_next = 0;
     void *clock_buf = nullptr;            // pifu_clock_probe: [8 XCDs][shader ticks, real-time ticks]
     // arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default), 1 = bf16 x 3 split precision on the bf16 matrix cores
     int precision = 0;

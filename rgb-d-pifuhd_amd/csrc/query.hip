@@ -80,6 +80,7 @@ struct GemmArgs {
         int pad;
     } steps[40];
     int nsteps;
+    int *tile_ctr;   // k_mlp_gemm_dyn: 8 work-queue counters (one per XCD label), zero at launch
     int dbg;   // EXPERIMENTS builds: bit0 skip Y stores, bit1 skip statistics, bit2 skip column init, bit3 skip MFMAs
 };
 
@@ -1535,6 +1536,21 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
 
 static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st);
 
+// work-queue counters of one k_mlp_gemm_dyn launch: a ring of zeroed 8-int slots, re-zeroed (stream-ordered) on wrap
+static int *next_tile_counters(pifu_ctx *ctx, hipStream_t st)
+{
+    constexpr int SLOTS = 4096;
+    if (!ctx->tile_ctr) {
+        if (hipMalloc(&ctx->tile_ctr, SLOTS * 8 * sizeof(int)) != hipSuccess) { ctx->tile_ctr = nullptr; return nullptr; }
+        ctx->tile_ctr_next = SLOTS;      // forces the first memset
+    }
+    if (ctx->tile_ctr_next >= SLOTS) {
+        if (hipMemsetAsync(ctx->tile_ctr, 0, SLOTS * 8 * sizeof(int), st) != hipSuccess) return nullptr;
+        ctx->tile_ctr_next = 0;
+    }
+    return (int *)ctx->tile_ctr + 8 * ctx->tile_ctr_next++;
+}
+
 // exact-fp32 GEMM dispatch (EXPERIMENTS builds: PIFU_GEMM_VARIANT=13 selects the rejected 256-row tile kernel when a
 // 256-row tile cannot straddle a chunk; PIFU_GEMM_DBG ablates parts of the kernel for timing studies)
 static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
@@ -1550,6 +1566,12 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     }
     GemmArgs b = a;
     if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
+    if (ctx->gemm_variant == 22 && a.ldw / 32 >= 3) {      // persistent blocks, dynamic per-XCD tile queues
+        const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
+        b.tile_ctr = next_tile_counters(ctx, st);
+        b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
+        if (b.tile_ctr) { hipLaunchKernelGGL(k_mlp_gemm_dyn, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b); return; }
+    }
     if (ctx->gemm_variant == 20) {      // persistent blocks with cross-tile prefetch (rejected: same speed, see gemm_experiments.inc)
         const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
         b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
