@@ -388,6 +388,7 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
+template <bool PRIO>
 __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
 {
     constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
@@ -403,12 +404,15 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     const int chunk_id = tile_m / a.g.tpc;
     const size_t row0 = (size_t)tile_m * BM;
     const int col0 = tile_n * BN;
+    // EXPERIMENTS builds (PIFU_GEMM_DBG): bit 16 = every block LOADS tile (0, 0) (memory system out of the picture)
+    const size_t row0_ld = (PIFU_DBG(a) & 16) ? 0 : row0;
+    const int col0_ld = (PIFU_DBG(a) & 16) ? 0 : col0;
 
     const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
     const unsigned kb = kq * 16;
     const int nsteps = a.ldw / TBK;
     const unsigned ldw4 = (unsigned)a.ldw * 4u;
-    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
+    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0_ld * a.ldw);
     const unsigned voW = (unsigned)sr * ldw4 + kb;
 
     float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     int c_seg = 0, c_left = a.seg[0].width / TBK;
     unsigned c_ks4 = 0, c_kw4 = 0;
     unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
-    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0 * (size_t)a.seg[0].ld);
+    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0_ld * (size_t)a.seg[0].ld);
     __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
     __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
     float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
             c_left = (c_seg == 1 ? a.seg[1].width : a.seg[2].width) / TBK;                                 \
             c_ks4 = 0;                                                                                     \
             c_ld4 = (unsigned)nld_ * 4u;                                                                   \
-            c_rA = buf_rsrc(np_ + row0 * (size_t)nld_);                                                    \
+            c_rA = buf_rsrc(np_ + row0_ld * (size_t)nld_);                                                 \
             c_rsc = buf_rsrc(nsc_ + (size_t)chunk_id * nsld_);                                             \
             c_rsh = buf_rsrc(nsh_ + (size_t)chunk_id * nsld_);                                             \
             c_slope = nmd_ == 0 ? 1.f : 0.01f;                                                             \
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     BUF_GLOAD(0)
-    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
+    if (a.colQ && !(PIFU_DBG(a) & 4)) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
         const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
         const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);     // descriptors stay block-uniform (SGPRs)
         const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
         if (more) BUF_GLOAD(step + 1)
         const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
         const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        __builtin_amdgcn_s_setprio(3);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
                 acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (more) BUF_LSTORE(buf ^ 1)
         __syncthreads();
     }
@@ -548,9 +552,139 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
         const int rr = (mt_) * 32 + (r & 3) + 8 * (r >> 2);                                                \
         const float v = acc_[r] + bias_;                                                                   \
-        buf_store1(v, rY, voY, (unsigned)rr * ldy4 + (nt_) * 128u);                                        \
+        if (!(PIFU_DBG(a) & 1)) buf_store1(v, rY, voY, (unsigned)rr * ldy4 + (nt_) * 128u);                \
         if (!(CHECK_) || wm * 64 + rr + 4 * h < nvalid) { s_ += v; q_ = fmaf(v, v, q_); }                  \
     }
+    if (nvalid >= BM) {
+        BUF_EPI(acc00, 0, 0, bias0, s0, q0, false) BUF_EPI(acc10, 1, 0, bias0, s0, q0, false)
+        BUF_EPI(acc01, 0, 1, bias1, s1, q1, false) BUF_EPI(acc11, 1, 1, bias1, s1, q1, false)
+    } else {
+        BUF_EPI(acc00, 0, 0, bias0, s0, q0, true) BUF_EPI(acc10, 1, 0, bias0, s0, q0, true)
+        BUF_EPI(acc01, 0, 1, bias1, s1, q1, true) BUF_EPI(acc11, 1, 1, bias1, s1, q1, true)
+    }
+    if (a.partial && !(PIFU_DBG(a) & 2)) {
+        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+        s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+        if (lane < 32) {
+            red[(0 * 2 + wm) * BN + wn * 64 + j] = s0;
+            red[(1 * 2 + wm) * BN + wn * 64 + j] = q0;
+            red[(0 * 2 + wm) * BN + wn * 64 + 32 + j] = s1;
+            red[(1 * 2 + wm) * BN + wn * 64 + 32 + j] = q1;
+        }
+        __syncthreads();
+        if (tid < BN)
+            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
+                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mlp_gemm_tri: k_mlp_gemm_buf with a SINGLE LDS buffer (36 KB) and a register budget of 168, so that THREE blocks fit a
+// CU (three waves per SIMD).  Stamps of the two-block kernels show that a second resident block only adds 8 % to what one
+// block delivers alone: with two waves per SIMD the matrix pipe idles whenever both are outside their MFMA phase.  A
+// K step costs one more barrier here (the tile is overwritten in place once every wave has read its fragments), which the
+// two other resident blocks cover.  Same tiles, k order and statistics as k_mlp_gemm_buf: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
+{
+    constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];   // [A|B], single buffer: 36 KB, three blocks per CU
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q_tile = blockIdx.x;
+    const int xcd = q_tile & 7, slot = q_tile >> 3;
+    const int tile_n = slot % a.ntn;
+    const int tile_m = (slot / a.ntn) * 8 + xcd;
+    if (tile_m >= a.ntm) return;
+    const int chunk_id = tile_m / a.g.tpc;
+    const size_t row0 = (size_t)tile_m * BM, row0_ld = row0;
+    const int col0 = tile_n * BN;
+
+    const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
+    const unsigned kb = kq * 16;
+    const int nsteps = a.ldw / TBK;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
+    const unsigned voW = (unsigned)sr * ldw4 + kb;
+
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
+    float rslope = 1.f;
+
+    // cursor of the next K step to fetch: every per-segment quantity is resolved when the cursor ENTERS a segment (a rare
+    // uniform branch), so a step costs a handful of scalar adds instead of a ~70-instruction select chain
+    int c_seg = 0, c_left = a.seg[0].width / TBK;
+    unsigned c_ks4 = 0, c_kw4 = 0;
+    unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
+    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0 * (size_t)a.seg[0].ld);
+    __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
+    __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
+    float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
+    unsigned voA = (unsigned)sr * c_ld4 + kb;
+    // norm affine + LeakyReLU on packed pairs: t = v * sc + sh;  v = max(t, slope * t)
+
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    BUF_GLOAD(0)
+    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
+        const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
+        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);     // descriptors stay block-uniform (SGPRs)
+        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
+        const float wz0 = a.colwz ? a.colwz[col0 + wn * 64 + j] : 0.f, wz1 = a.colwz ? a.colwz[col0 + wn * 64 + 32 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+            const unsigned ciA = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so, 0);
+            const unsigned ciB = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so + 128u, 0);
+            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
+            const unsigned qA = ciA * ldq4 + (unsigned)(wn * 64 + j) * 4u, qB = ciB * ldq4 + (unsigned)(wn * 64 + j) * 4u;
+            acc00[r] = fmaf(wz0, zA, buf_load1(rQ, qA, 0));
+            acc01[r] = fmaf(wz1, zA, buf_load1(rQ, qA, 128));
+            acc10[r] = fmaf(wz0, zB, buf_load1(rQ, qB, 0));
+            acc11[r] = fmaf(wz1, zB, buf_load1(rQ, qB, 128));
+        }
+    }
+    BUF_LSTORE(0)
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        if (more) BUF_GLOAD(step + 1)
+        const float *A = lds + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        const float *B = lds + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
+            const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();                 // every wave has read its fragments: the tile may be overwritten
+        if (more) BUF_LSTORE(0)
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
+    const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
+    const unsigned ldy4 = (unsigned)a.ldy * 4u;
+    const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;
+    const float bias0 = a.bias[col0 + wn * 64 + j], bias1 = a.bias[col0 + wn * 64 + 32 + j];
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     if (nvalid >= BM) {
         BUF_EPI(acc00, 0, 0, bias0, s0, q0, false) BUF_EPI(acc10, 1, 0, bias0, s0, q0, false)
         BUF_EPI(acc01, 0, 1, bias1, s1, q1, false) BUF_EPI(acc11, 1, 1, bias1, s1, q1, false)
@@ -1566,30 +1700,39 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     }
     GemmArgs b = a;
     if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
-    if (ctx->gemm_variant == 22 && a.ldw / 32 >= 3) {      // persistent blocks, dynamic per-XCD tile queues
+    if ((ctx->gemm_variant == 22 || ctx->gemm_variant == 25) && a.ldw / 32 >= 3) {      // persistent blocks, dynamic per-XCD tile queues (25: no s_setprio)
         const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
         b.tile_ctr = next_tile_counters(ctx, st);
         b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
-        if (b.tile_ctr) { hipLaunchKernelGGL(k_mlp_gemm_dyn, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b); return; }
+        if (b.tile_ctr) {
+            if (ctx->gemm_variant == 22) hipLaunchKernelGGL(k_mlp_gemm_dyn<true>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
+            else hipLaunchKernelGGL(k_mlp_gemm_dyn<false>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
+            return;
+        }
     }
-    if (ctx->gemm_variant == 20) {      // persistent blocks with cross-tile prefetch (rejected: same speed, see gemm_experiments.inc)
+    if (ctx->gemm_variant == 20 || ctx->gemm_variant == 26) {      // persistent blocks with cross-tile prefetch (26: no s_setprio) (rejected: same speed, see gemm_experiments.inc)
         const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
         b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
-        hipLaunchKernelGGL(k_mlp_gemm_pers, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
+        if (ctx->gemm_variant == 20) hipLaunchKernelGGL(k_mlp_gemm_pers<true>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(k_mlp_gemm_pers<false>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
     } else if (ctx->gemm_variant == 6) {
         b.stamps = (ctx->debug_buf && a.ldw == 1024) ? (unsigned long long *)ctx->debug_buf : nullptr;   // coarse L1 only
         hipLaunchKernelGGL(k_mlp_gemm_buf2, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
     } else if (ctx->gemm_variant == 4)
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
     else
-        hipLaunchKernelGGL(k_mlp_gemm_buf, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
 #else
     if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else if (ctx->gemm_variant == 23)
+        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
     else if (ctx->gemm_variant == 21 && a.ntn % 2 == 0)
         hipLaunchKernelGGL(k_mlp_gemm_wide, dim3((unsigned)round_up(a.ntm, 8) * (a.ntn / 2)), dim3(256), 0, st, a);
+    else if (ctx->gemm_variant == 24)
+        hipLaunchKernelGGL(k_mlp_gemm_buf<false>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(k_mlp_gemm_buf, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 #endif
 }
 
