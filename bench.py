@@ -12,7 +12,7 @@ inside the timed region (weak scaling: 256^3 queries per GPU).  Feature maps com
 filter_global / filter_local of a synthetic 1024 px image with name-seeded random weights and are
 resident in HBM before the timed region, as are the weights; lattice points are generated on the device.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel k_mlp_gemm_buf (exact-fp32 MFMA): algorithmic
+One JSON line on rank 0.  `roofline` is for the dominant kernel k_mlp_gemm_tri (exact-fp32 MFMA): algorithmic
 FLOPs of its launches / their summed HIP-event durations, against the 157.3 TFLOP/s fp32-matrix peak.
 `cpu_baseline` times the CPU oracle (kind "port": the reference's Python cannot travel to the GPU box) on
 a bounded sample of the same workload, rank 0, N = 1 only.
@@ -253,7 +253,7 @@ def main():
         'executed_gemm_tflops_over_step': round(gemm_flops.value * world / elapsed / 1e12, 2),
         'canonical_equivalent_tflops': round(value * 1e6 * FLOP_PER_QUERY / 1e12, 2),
         'roofline': {
-            'kernel': 'k_mlp_gemm_buf', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
+            'kernel': 'k_mlp_gemm_tri', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': traffic,
             'launches': gemm_n.value, 'avg_launch_ms': round(gemm_ms.value / max(gemm_n.value, 1), 4),
             'alg_gflop_per_launch': round(gemm_flops.value / max(gemm_n.value, 1) / 1e9, 3),

@@ -184,7 +184,7 @@ int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const
 int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
                           float *out, pifu_stream stream);
 
-/* ---- measurement hook (bench.py / profiles): HIP-event timing of every k_mlp_gemm launch on its own stream --
+/* ---- measurement hook (bench.py / profiles): HIP-event timing of every MLP GEMM launch (k_mlp_gemm_tri) on its own stream --
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms),
  * number of launches and the ALGORITHMIC FLOPs of those launches (2 * valid points * Cout * Cin). */
 int pifu_profile_enable(pifu_ctx *ctx, int on);

@@ -15,10 +15,11 @@
 //   row tile never straddles two chunks; padded rows carry zero features and are masked out of the
 //   statistics.
 //
-// The dominant kernel is k_mlp_gemm: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), 128x128x32 block tile,
-// 4 waves each owning a 64x64 output tile (2x2 MFMA tiles, 64 accumulator VGPRs), register-staged
-// double-buffered LDS with the norm+LeakyReLU prologue fused into the staging pass, per-column
-// (sum, sum^2) partials for the next norm fused into the epilogue (deterministic: no atomics).
+// The dominant kernel is k_mlp_gemm_tri (k_mlp_gemm_buf and k_mlp_gemm are its predecessors, kept for A/B): exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32), 128x128x32 block tile, 4 waves each owning a 64x64 output tile (2x2 MFMA tiles, 64
+// accumulator VGPRs), register-staged LDS (one 36 KB buffer, three blocks per CU) with the norm+LeakyReLU prologue
+// fused into the staging pass, per-column (sum, sum^2) partials for the next norm fused into the epilogue
+// (deterministic: no atomics).
 #include "pifu_internal.h"
 
 #include <math.h>
@@ -1720,19 +1721,21 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
         hipLaunchKernelGGL(k_mlp_gemm_buf2, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
     } else if (ctx->gemm_variant == 4)
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
-    else
+    else if (ctx->gemm_variant == 28)
         hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+    else
+        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
 #else
     if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else if (ctx->gemm_variant == 23)
-        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else if (ctx->gemm_variant == 28)   // the two-blocks-per-CU, double-buffered predecessor of the default
+        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
     else if (ctx->gemm_variant == 21 && a.ntn % 2 == 0)
         hipLaunchKernelGGL(k_mlp_gemm_wide, dim3((unsigned)round_up(a.ntm, 8) * (a.ntn / 2)), dim3(256), 0, st, a);
     else if (ctx->gemm_variant == 24)
         hipLaunchKernelGGL(k_mlp_gemm_buf<false>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else                                // default: three blocks per CU
+        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 #endif
 }
 

@@ -41,7 +41,7 @@ def pmc(dirname):
 
 fetch, write, sq = pmc('pmc_fetch'), pmc('pmc_write'), pmc('pmc_sq')
 summary = {}
-GEMM = 'k_mlp_gemm_buf' if 'k_mlp_gemm_buf' in fetch else 'k_mlp_gemm'
+GEMM = next((k for k in ('k_mlp_gemm_tri', 'k_mlp_gemm_buf') if k in fetch), 'k_mlp_gemm')
 for k in (GEMM, 'k_sample_col', 'k_expand', 'k_last_layer'):
     f = fetch.get(k, {}).get('FETCH_SIZE', [])
     w = write.get(k, {}).get('WRITE_SIZE', [])
