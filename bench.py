@@ -97,7 +97,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-genmesh', action='store_true')
-    ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 measurement')
+    ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
                     help="feature maps from the real encoders (filter) or seeded random maps of the same shape")
@@ -264,32 +264,40 @@ def main():
         },
     }
 
-    # ---- opt-in split precision (bf16 x 3 on the bf16 matrix cores): reported beside the headline, never as `value`
-    split = None
+    # ---- opt-in split precision on the 16-bit matrix cores (bf16 x 3, fp16 x 3): reported beside the headline, never as `value`
+    split_fields = {}
     if world == 1 and not args.no_split_precision:
-        _lib.call('pifu_set_precision', h, 1)
-        step()
-        fence()
-        _lib.call('pifu_profile_read', h, None, None, None, 1)
-        _lib.call('pifu_profile_enable', h, 1)
-        s0 = time.perf_counter()
-        field_split = None
-        for _ in range(args.steps):
-            field_split = step()
-        fence()
-        s_el = time.perf_counter() - s0
-        _lib.call('pifu_profile_enable', h, 0)
-        sm, sn, sf = C.c_double(0), C.c_int64(0), C.c_double(0)
-        _lib.call('pifu_profile_read', h, C.byref(sm), C.byref(sn), C.byref(sf), 1)
-        _lib.call('pifu_set_precision', h, 0)
-        split = {'arithmetic': 'bf16x3 split (hi*hi + lo*hi + hi*lo, fp32 accumulate) on v_mfma_f32_32x32x16_bf16; opt-in via '
-                               'pifu_set_precision(ctx, 1)',
-                 'value': round(total * args.steps / s_el / 1e6, 3), 'unit': 'Mqueries/s',
-                 'ms_per_step': round(s_el / max(args.steps, 1) * 1e3, 3),
-                 'gemm_algorithmic_tflops': round(sf.value / (sm.value * 1e-3) / 1e12, 2) if sm.value > 0 else None,
-                 'max_abs_diff_vs_fp32_path': float((field_split - field).abs().max().item())}
-        log(f"split precision: {split['value']} Mq/s")
-        out['split_precision'] = split
+        arith = {1: 'bf16x3 split (hi*hi + lo*hi + hi*lo, fp32 accumulate) on v_mfma_f32_32x32x16_bf16; opt-in via pifu_set_precision(ctx, 1)',
+                 2: 'fp16x3 split (same three products on v_mfma_f32_32x32x16_f16, weight planes scaled by 2^11: operands good to 2^-22); '
+                    'opt-in via pifu_set_precision(ctx, 2)'}
+        for mode, key in ((1, 'split_precision'), (2, 'split_precision_fp16x3')):
+            _lib.call('pifu_set_precision', h, mode)
+            try:
+                step()
+                fence()
+                _lib.call('pifu_profile_read', h, None, None, None, 1)
+                _lib.call('pifu_profile_enable', h, 1)
+                s0 = time.perf_counter()
+                field_split = None
+                for _ in range(args.steps):
+                    field_split = step()
+                fence()
+                s_el = time.perf_counter() - s0
+                _lib.call('pifu_profile_enable', h, 0)
+                sm, sn, sf = C.c_double(0), C.c_int64(0), C.c_double(0)
+                _lib.call('pifu_profile_read', h, C.byref(sm), C.byref(sn), C.byref(sf), 1)
+                split_fields[key] = field_split
+                out[key] = {'arithmetic': arith[mode],
+                            'value': round(total * args.steps / s_el / 1e6, 3), 'unit': 'Mqueries/s',
+                            'ms_per_step': round(s_el / max(args.steps, 1) * 1e3, 3),
+                            'gemm_algorithmic_tflops': round(sf.value / (sm.value * 1e-3) / 1e12, 2) if sm.value > 0 else None,
+                            'max_abs_diff_vs_fp32_path': float((field_split - field).abs().max().item())}
+                log(f"{key}: {out[key]['value']} Mq/s, max diff {out[key]['max_abs_diff_vs_fp32_path']:.2e}")
+            except Exception as e:      # the metric line must still be printed
+                out[key] = {'error': repr(e)}
+            finally:
+                _lib.call('pifu_profile_enable', h, 0)
+                _lib.call('pifu_set_precision', h, 0)
 
     # ---- parity spot check + CPU baseline (oracle = checker; never the thing measured as `value`) -----
     if world == 1 and not args.no_cpu_baseline:
@@ -328,6 +336,8 @@ def main():
                                       f'{ncores} of {os.cpu_count()} host threads',
         }
         out['parity_check_max_abs_diff'] = float(np.abs(got - want).max())
+        for key, fld in split_fields.items():      # the opt-in arithmetics against the same oracle sample
+            out[key]['max_abs_diff_vs_cpu_oracle'] = float(np.abs(fld[first:first + npts].cpu().numpy() - want).max())
 
     # ---- second half of the metric: end-to-end gen_mesh wall time (single GPU) ---------------------------
     if world == 1 and not args.no_genmesh and args.features == 'filter':

@@ -80,7 +80,9 @@ int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight,
                        const float *norm_weight, const float *norm_bias,
                        const float *running_mean, const float *running_var);
 /* Arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default, ~1e-6 from the reference); 1 = bf16 x 3 split precision
- * on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation; ~1e-5 on the occupancy, inside the 1e-4 contract). */
+ * on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation; ~1e-5 on the occupancy, inside the 1e-4 contract);
+ * 2 = fp16 x 3: the same three products on the fp16 matrix cores with the weight planes scaled by 2^11 (operands good to
+ * 2^-22: ~1e-6 on the occupancy; needs |w| < 32 and |activations| < 65504, the first is checked). */
 int pifu_set_precision(pifu_ctx *ctx, int mode);
 /* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
  * z_div = z_size of the COARSE net's options. */

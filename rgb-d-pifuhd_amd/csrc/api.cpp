@@ -150,10 +150,16 @@ extern "C" int64_t pifu_workspace_bytes(pifu_ctx *ctx)
     return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes) : 0;
 }
 
-// 0 = exact fp32 MFMA (default); 1 = bf16 x 3 split precision (fp32 accumulate, ~1e-5 on the occupancy)
+// 0 = exact fp32 MFMA (default); 1 = bf16 x 3 split precision (~1e-5 on the occupancy); 2 = fp16 x 3 (~1e-6)
 extern "C" int pifu_set_precision(pifu_ctx *ctx, int mode)
 {
-    PIFU_REQUIRE(ctx && (mode == 0 || mode == 1), PIFU_ERR_INVALID, "pifu_set_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+    PIFU_REQUIRE(ctx && mode >= 0 && mode <= 2, PIFU_ERR_INVALID, "pifu_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (fp16x3)");
+    if (mode != ctx->precision) {      // the cached weight planes belong to one mode
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);
+        ctx->bf16_planes.clear();
+    }
     ctx->precision = mode;
     return PIFU_OK;
 }

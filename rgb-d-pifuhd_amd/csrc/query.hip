@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_wide(const GemmArgs a)
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_bf3: opt-in split-precision version of the MLP GEMM on the bf16 matrix cores.
+// k_mlp_gemm_split<0> (bf16 x 3) / <1> (fp16 x 3): opt-in split-precision versions of the MLP GEMM on the 16-bit matrix cores.
 // Every fp32 operand x is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32), and
 // the product is accumulated in fp32 as  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  (the lo*lo term, 2^-16 relative, is
 // dropped).  3 x v_mfma_f32_32x32x16_bf16 (32 cycles each) replace 8 x v_mfma_f32_32x32x2_f32 (64 cycles each) per
@@ -916,23 +916,52 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_wide(const GemmArgs a)
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__global__ void k_split_bf16(const float *W, __bf16 *hi, __bf16 *lo, size_t n)
+// F16 = 0: bf16 x 3 (above).  F16 = 1: fp16 x 3 - same three products on v_mfma_f32_32x32x16_f16, whose operands carry 11
+// significant bits instead of 8: x = hi + lo is then good to 2^-22 and the dropped lo*lo term is 2^-22 relative, i.e. the
+// result is within a few fp32 ulps of the exact-fp32 kernel's (measured ~1e-6 on the occupancy).  fp16 has 5 exponent bits,
+// so the weight planes are stored scaled by 2^11 (hi' = fp16(2048 w), lo' = fp16(2048 w - hi'): both in the normal range for
+// |w| < 32; checked when the planes are built), the activation planes unscaled (lo = fp16(a - hi) becomes subnormal for
+// |a| < 2^-3 and is then quantised to 2^-25 absolute - below fp32's own rounding of O(1) data; |a| must stay below 65 504),
+// all three products share the scale 2^11, the accumulators start from 2^11 x the column-init value and the epilogue
+// multiplies by 2^-11 (exact) before the bias.
+template <int F16> struct SplitT;
+template <> struct SplitT<0> {
+    typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
+    static __device__ __forceinline__ f32x16 mfma(V8 x, V8 y, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); }
+};
+template <> struct SplitT<1> {
+    typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
+    static __device__ __forceinline__ f32x16 mfma(V8 x, V8 y, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); }
+};
+
+template <int F16>
+__global__ void k_split_planes(const float *W, void *hi_, void *lo_, size_t n, int *bad)
 {
+    typedef typename SplitT<F16>::T T;
+    T *hi = (T *)hi_, *lo = (T *)lo_;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float x = W[i];
-    const __bf16 h = (__bf16)x;
+    const float x = W[i] * (F16 ? 2048.f : 1.f);
+    if (F16 && !(fabsf(x) < 65504.f)) *bad = 1;       // |w| >= 32 (or NaN): outside the scaled fp16 range
+    const T h = (T)x;
     hi[i] = h;
-    lo[i] = (__bf16)(x - (float)h);
+    lo[i] = (T)(x - (float)h);
 }
 
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
+template <int F16>
+__global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
 {
+    typedef typename SplitT<F16>::T T;
+    typedef typename SplitT<F16>::V8 V8;
+    typedef typename SplitT<F16>::V4 V4;
+    constexpr float WS = F16 ? 2048.f : 1.f, WSI = F16 ? (1.f / 2048.f) : 1.f;
     constexpr int TBK = 32;
     constexpr int RS = 32;                       // row stride in bf16 elements (64 B); 16-byte chunks XOR-swizzled by (row >> 2) & 3
     constexpr int PLANE = BM * RS;               // one [128][32] bf16 plane
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * PLANE];   // [buf][A_hi | A_lo | W_hi | W_lo] = 65,536 B
+    __shared__ __attribute__((aligned(16))) T lds[2 * 4 * PLANE];   // [buf][A_hi | A_lo | W_hi | W_lo] = 65,536 B
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -951,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
 
     // Operands are prefetched TWO K steps ahead into two register sets (step j lives in set j & 1): with the short
     // bf16 MFMA phase a one-step-ahead prefetch would stall on the global-load latency at every staging pass.
-    struct Stage { float4 a0, a1, a2, a3, sc, sh; bf16x8 wh0, wh1, wl0, wl1; float slope; };
+    struct Stage { float4 a0, a1, a2, a3, sc, sh; V8 wh0, wh1, wl0, wl1; float slope; };
     Stage S0, S1;
     S0.slope = S1.slope = 1.f;
 
@@ -978,12 +1007,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
         const char *hb = reinterpret_cast<const char *>(d_shift + (size_t)chunk_id * d_sld);               \
         S_.sc = *reinterpret_cast<const float4 *>(sb + kb4);                                               \
         S_.sh = *reinterpret_cast<const float4 *>(hb + kb4);                                               \
-        const char *whb = reinterpret_cast<const char *>(a.Whi + (step_) * TBK);                           \
-        const char *wlb = reinterpret_cast<const char *>(a.Wlo + (step_) * TBK);                           \
-        S_.wh0 = *reinterpret_cast<const bf16x8 *>(whb + wo0);                                             \
-        S_.wh1 = *reinterpret_cast<const bf16x8 *>(whb + wo1);                                             \
-        S_.wl0 = *reinterpret_cast<const bf16x8 *>(wlb + wo0);                                             \
-        S_.wl1 = *reinterpret_cast<const bf16x8 *>(wlb + wo1);                                             \
+        const char *whb = reinterpret_cast<const char *>((const T *)a.Whi + (step_) * TBK);                           \
+        const char *wlb = reinterpret_cast<const char *>((const T *)a.Wlo + (step_) * TBK);                           \
+        S_.wh0 = *reinterpret_cast<const V8 *>(whb + wo0);                                             \
+        S_.wh1 = *reinterpret_cast<const V8 *>(whb + wo1);                                             \
+        S_.wl0 = *reinterpret_cast<const V8 *>(wlb + wo0);                                             \
+        S_.wl1 = *reinterpret_cast<const V8 *>(wlb + wo1);                                             \
         const int nx_ = d_next < nsteps ? d_next : nsteps - 1;                                             \
         const GemmArgs::StepDesc &dn = a.steps[nx_];                                                       \
         d_ptr = dn.ptr; d_scale = dn.scale; d_shift = dn.shift; d_ld4 = dn.ld4; d_sld = dn.sld; d_mode = dn.mode; \
@@ -1007,10 +1036,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
         S_.sc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                       \
         S_.sh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                       \
         const size_t wo = (size_t)(col0 + wr) * a.ldw + kk + wq * 8;                                       \
-        S_.wh0 = *reinterpret_cast<const bf16x8 *>(a.Whi + wo);                                            \
-        S_.wh1 = *reinterpret_cast<const bf16x8 *>(a.Whi + wo + (size_t)64 * a.ldw);                       \
-        S_.wl0 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo);                                            \
-        S_.wl1 = *reinterpret_cast<const bf16x8 *>(a.Wlo + wo + (size_t)64 * a.ldw);                       \
+        S_.wh0 = *reinterpret_cast<const V8 *>((const T *)a.Whi + wo);                                            \
+        S_.wh1 = *reinterpret_cast<const V8 *>((const T *)a.Whi + wo + (size_t)64 * a.ldw);                       \
+        S_.wl0 = *reinterpret_cast<const V8 *>((const T *)a.Wlo + wo);                                            \
+        S_.wl1 = *reinterpret_cast<const V8 *>((const T *)a.Wlo + wo + (size_t)64 * a.ldw);                       \
     }                                                                                                      \
     }
     // transform, split into hi / lo and write one float4 (4 k) of A
@@ -1021,25 +1050,25 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
         float t2_ = fmaf(v_.z, S_.sc.z, S_.sh.z), t3_ = fmaf(v_.w, S_.sc.w, S_.sh.w);                      \
         t0_ = fmaxf(t0_, S_.slope * t0_); t1_ = fmaxf(t1_, S_.slope * t1_);                                \
         t2_ = fmaxf(t2_, S_.slope * t2_); t3_ = fmaxf(t3_, S_.slope * t3_);                                \
-        bf16x4 h_, l_;                                                                                     \
-        h_[0] = (__bf16)t0_; h_[1] = (__bf16)t1_; h_[2] = (__bf16)t2_; h_[3] = (__bf16)t3_;                \
-        l_[0] = (__bf16)(t0_ - (float)h_[0]); l_[1] = (__bf16)(t1_ - (float)h_[1]);                        \
-        l_[2] = (__bf16)(t2_ - (float)h_[2]); l_[3] = (__bf16)(t3_ - (float)h_[3]);                        \
+        V4 h_, l_;                                                                                         \
+        h_[0] = (T)t0_; h_[1] = (T)t1_; h_[2] = (T)t2_; h_[3] = (T)t3_;                            \
+        l_[0] = (T)(t0_ - (float)h_[0]); l_[1] = (T)(t1_ - (float)h_[1]);                                  \
+        l_[2] = (T)(t2_ - (float)h_[2]); l_[3] = (T)(t3_ - (float)h_[3]);                                  \
         const int row_ = sr + 32 * (p_);                                                                   \
-        __bf16 *d_ = (base_) + row_ * RS + (((kq >> 1) ^ ((row_ >> 2) & 3)) << 3) + (kq & 1) * 4;           \
-        *reinterpret_cast<bf16x4 *>(d_) = h_;                                                              \
-        *reinterpret_cast<bf16x4 *>(d_ + PLANE) = l_;                                                      \
+        T *d_ = (base_) + row_ * RS + (((kq >> 1) ^ ((row_ >> 2) & 3)) << 3) + (kq & 1) * 4;           \
+        *reinterpret_cast<V4 *>(d_) = h_;                                                              \
+        *reinterpret_cast<V4 *>(d_ + PLANE) = l_;                                                      \
     }
 #define BF3_LSTORE(S_, buf_)                                                                               \
     {                                                                                                      \
-        __bf16 *base = lds + (buf_) * 4 * PLANE;                                                           \
+        T *base = lds + (buf_) * 4 * PLANE;                                                               \
         BF3_STA(S_, base, 0, a0) BF3_STA(S_, base, 1, a1) BF3_STA(S_, base, 2, a2) BF3_STA(S_, base, 3, a3) \
         /* rows wr and wr + 64 have the same (row >> 2) & 3, so one swizzled chunk serves both */          \
-        __bf16 *wd = base + 2 * PLANE + wr * RS + ((wq ^ ((wr >> 2) & 3)) << 3);                           \
-        *reinterpret_cast<bf16x8 *>(wd) = S_.wh0;                                                          \
-        *reinterpret_cast<bf16x8 *>(wd + 64 * RS) = S_.wh1;                                                \
-        *reinterpret_cast<bf16x8 *>(wd + PLANE) = S_.wl0;                                                  \
-        *reinterpret_cast<bf16x8 *>(wd + PLANE + 64 * RS) = S_.wl1;                                        \
+        T *wd = base + 2 * PLANE      + wr * RS + ((wq ^ ((wr >> 2) & 3)) << 3);                           \
+        *reinterpret_cast<V8 *>(wd) = S_.wh0;                                                          \
+        *reinterpret_cast<V8 *>(wd + 64 * RS) = S_.wh1;                                                \
+        *reinterpret_cast<V8 *>(wd + PLANE) = S_.wl0;                                                  \
+        *reinterpret_cast<V8 *>(wd + PLANE + 64 * RS) = S_.wl1;                                        \
     }
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
@@ -1053,10 +1082,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
             const int ciA = a.colidx[rowA], ciB = a.colidx[rowB];
             const float zA = a.zf[rowA], zB = a.zf[rowB];
             const float *qA = a.colQ + (size_t)ciA * a.ldq + a.qoff, *qB = a.colQ + (size_t)ciB * a.ldq + a.qoff;
-            acc00[r] = fmaf(wz0, zA, qA[c0]);
-            acc01[r] = fmaf(wz1, zA, qA[c1]);
-            acc10[r] = fmaf(wz0, zB, qB[c0]);
-            acc11[r] = fmaf(wz1, zB, qB[c1]);
+            acc00[r] = WS * fmaf(wz0, zA, qA[c0]);
+            acc01[r] = WS * fmaf(wz1, zA, qA[c1]);
+            acc10[r] = WS * fmaf(wz0, zB, qB[c0]);
+            acc11[r] = WS * fmaf(wz1, zB, qB[c1]);
         }
     }
 
@@ -1065,28 +1094,28 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
     const int fo0 = frow * RS + (((0 + fh) ^ fsw) << 3), fo1 = frow * RS + (((2 + fh) ^ fsw) << 3);
 #define BF3_COMPUTE(buf_)                                                                                  \
     {                                                                                                      \
-        const __bf16 *T = lds + (buf_) * 4 * PLANE;                                                        \
+        const T *Tb = lds + (buf_) * 4 * PLANE;                                                           \
         _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                 \
             const int fo = kb == 0 ? fo0 : fo1;                                                            \
-            const __bf16 *Ah = T + (wm * 64) * RS + fo, *Al = Ah + PLANE;                                  \
-            const __bf16 *Bh = T + 2 * PLANE + (wn * 64) * RS + fo, *Bl = Bh + PLANE;                      \
-            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(Ah), ah1 = *reinterpret_cast<const bf16x8 *>(Ah + 32 * RS); \
-            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(Al), al1 = *reinterpret_cast<const bf16x8 *>(Al + 32 * RS); \
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bh), bh1 = *reinterpret_cast<const bf16x8 *>(Bh + 32 * RS); \
-            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(Bl), bl1 = *reinterpret_cast<const bf16x8 *>(Bl + 32 * RS); \
+            const T *Ah = Tb + (wm * 64) * RS + fo, *Al = Ah + PLANE;                                      \
+            const T *Bh = Tb + 2 * PLANE + (wn * 64) * RS + fo, *Bl = Bh + PLANE;                          \
+            const V8 ah0 = *reinterpret_cast<const V8 *>(Ah), ah1 = *reinterpret_cast<const V8 *>(Ah + 32 * RS); \
+            const V8 al0 = *reinterpret_cast<const V8 *>(Al), al1 = *reinterpret_cast<const V8 *>(Al + 32 * RS); \
+            const V8 bh0 = *reinterpret_cast<const V8 *>(Bh), bh1 = *reinterpret_cast<const V8 *>(Bh + 32 * RS); \
+            const V8 bl0 = *reinterpret_cast<const V8 *>(Bl), bl1 = *reinterpret_cast<const V8 *>(Bl + 32 * RS); \
             /* small terms first, the dominant hi*hi product last */                                       \
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);                     \
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);                     \
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);                     \
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);                     \
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);                     \
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);                     \
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);                     \
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);                     \
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);                     \
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);                     \
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);                     \
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);                     \
+            acc00 = SplitT<F16>::mfma(al0, bh0, acc00);                     \
+            acc01 = SplitT<F16>::mfma(al0, bh1, acc01);                     \
+            acc10 = SplitT<F16>::mfma(al1, bh0, acc10);                     \
+            acc11 = SplitT<F16>::mfma(al1, bh1, acc11);                     \
+            acc00 = SplitT<F16>::mfma(ah0, bl0, acc00);                     \
+            acc01 = SplitT<F16>::mfma(ah0, bl1, acc01);                     \
+            acc10 = SplitT<F16>::mfma(ah1, bl0, acc10);                     \
+            acc11 = SplitT<F16>::mfma(ah1, bl1, acc11);                     \
+            acc00 = SplitT<F16>::mfma(ah0, bh0, acc00);                     \
+            acc01 = SplitT<F16>::mfma(ah0, bh1, acc01);                     \
+            acc10 = SplitT<F16>::mfma(ah1, bh0, acc10);                     \
+            acc11 = SplitT<F16>::mfma(ah1, bh1, acc11);                     \
         }                                                                                                  \
     }
     // step t: issue the loads of step t+2 (into the set step t used), compute step t, stage step t+1 (other set)
@@ -1127,6 +1156,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
     int nvalid = chunk_len(a.g, chunk_id) - local0;
     nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
     float *red = reinterpret_cast<float *>(lds);
+    (void)WSI;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = col0 + wn * 64 + nt * 32 + j;
@@ -1138,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_bf3(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = acc[r] + bias;
+                const float v = F16 ? fmaf(acc[r], WSI, bias) : acc[r] + bias;
                 a.Y[(row0 + row) * (size_t)a.ldy + col] = v;
                 if (row < nvalid) { s += v; q = fmaf(v, v, q); }
             }
@@ -1807,12 +1837,13 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                 ctx->prof_used += 2;
                 PIFU_HIP(hipEventRecord(e0, st));
             }
-            if (ctx->precision == 1) {
+            if (ctx->precision != 0) {
                 if (!table_ok) a.nsteps = 0;
                 int rc2 = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
                 if (rc2) return rc2;
                 a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
-                hipLaunchKernelGGL(k_mlp_gemm_bf3, dim3(nblocks), dim3(256), 0, st, a);
+                if (ctx->precision == 2) hipLaunchKernelGGL(k_mlp_gemm_split<1>, dim3(nblocks), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(k_mlp_gemm_split<0>, dim3(nblocks), dim3(256), 0, st, a);
             } else
             {
 #ifdef PIFU_GEMM_EXPERIMENTS
@@ -1976,16 +2007,30 @@ static int prof_begin(pifu_ctx *ctx, hipStream_t st, hipEvent_t *e1)
     return PIFU_OK;
 }
 
-// bf16 hi / lo planes of a packed fp32 weight matrix, built on the device the first time the matrix is used
+// hi / lo planes (bf16, or fp16 scaled by 2^11) of a packed fp32 weight matrix, built on the device the first time the
+// matrix is used in the current precision mode (pifu_set_precision drops the planes of the other mode)
 static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st)
 {
     auto it = ctx->bf16_planes.find((const void *)W);
     if (it == ctx->bf16_planes.end() || it->second.n != n) {
         if (it != ctx->bf16_planes.end()) { (void)hipFree(it->second.hi); ctx->bf16_planes.erase(it); }
         void *p = nullptr;
-        PIFU_HIP(hipMalloc(&p, n * 2 * sizeof(__bf16)));
+        PIFU_HIP(hipMalloc(&p, n * 2 * sizeof(__bf16) + 16));
         pifu_ctx::Planes pl{p, (char *)p + n * sizeof(__bf16), n};
-        hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, (__bf16 *)pl.hi, (__bf16 *)pl.lo, n);
+        int *bad = (int *)((char *)p + n * 2 * sizeof(__bf16));
+        PIFU_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+        if (ctx->precision == 2) {
+            hipLaunchKernelGGL(k_split_planes<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, pl.hi, pl.lo, n, bad);
+            int host_bad = 0;
+            PIFU_HIP(hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+            PIFU_HIP(hipStreamSynchronize(st));
+            if (host_bad) {
+                (void)hipFree(p);
+                PIFU_REQUIRE(false, PIFU_ERR_INVALID, "fp16x3 precision needs finite weights with |w| < 32 (set precision 0 or 1)");
+            }
+        } else {
+            hipLaunchKernelGGL(k_split_planes<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, pl.hi, pl.lo, n, bad);
+        }
         it = ctx->bf16_planes.emplace((const void *)W, pl).first;
     }
     *hi = (const __bf16 *)it->second.hi;
@@ -2013,13 +2058,14 @@ static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
 {
     const int nblocks = (int)round_up(a.ntm, 8) * a.ntn;
     fill_step_table(a, (int64_t)a.ntm * BM);
-    if (ctx->precision == 1) {
+    if (ctx->precision != 0) {
         int rc = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
         if (rc) return rc;
         hipEvent_t e1b;
         rc = prof_begin(ctx, st, &e1b);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_mlp_gemm_bf3, dim3(nblocks), dim3(256), 0, st, a);
+        if (ctx->precision == 2) hipLaunchKernelGGL(k_mlp_gemm_split<1>, dim3(nblocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_mlp_gemm_split<0>, dim3(nblocks), dim3(256), 0, st, a);
         if (e1b) { PIFU_HIP(hipEventRecord(e1b, st)); ctx->prof_flops += flops; ctx->prof_launches += 1; }
         return PIFU_OK;
     }

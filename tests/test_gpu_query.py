@@ -205,6 +205,35 @@ def test_split_precision_bf16x3_within_contract(gold):
     assert np.array_equal(netMR.get_preds()[0, 0].cpu().numpy(), exact)
 
 
+def test_split_precision_fp16x3_is_fp32_grade(gold):
+    """Opt-in fp16 x 3 GEMMs (pifu_set_precision(ctx, 2)): three fp16 products with the weight planes scaled by 2^11 carry
+    operands good to 2^-22, so the occupancy stays within a few 1e-6 of the exact-fp32 path (10x tighter than bf16 x 3) and
+    well inside the 1e-4 contract against the reference's golden vectors; weights outside the scaled fp16 range are refused."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build()
+    calib = calib_tensor()
+    netMR.query(seeded_points(3, 700), calib)
+    exact = netMR.get_preds()[0, 0].cpu().numpy()
+    _lib.call('pifu_set_precision', netMR._ctx.h, 2)
+    try:
+        netMR.query(seeded_points(3, 700), calib)
+        split = netMR.get_preds()[0, 0].cpu().numpy()
+        assert np.abs(split - gold['group_a_fine']).max() < TOL
+        assert np.abs(netG.preds[0, 0].cpu().numpy() - gold['group_a_coarse']).max() < TOL
+        d = np.abs(split - exact).max()
+        assert 0 < d < 1e-5, d                                 # a different arithmetic, at fp32 rounding level
+        pts = seeded_points(4, 1200, lim=1.0)
+        out = []
+        for s in range(0, 1200, 500):
+            netMR.query(pts[:, :, s:s + 500], calib)
+            out.append(netMR.get_preds()[0, 0].cpu().numpy())
+        assert np.abs(np.concatenate(out) - gold['group_b_fine']).max() < TOL
+    finally:
+        _lib.call('pifu_set_precision', netMR._ctx.h, 0)
+    netMR.query(seeded_points(3, 700), calib)
+    assert np.array_equal(netMR.get_preds()[0, 0].cpu().numpy(), exact)
+
+
 def test_supervised_forward_matches_reference():
     """query(labels=...) + get_error() (forward only) against the reference fixture."""
     import os
