@@ -234,6 +234,25 @@ def test_split_precision_fp16x3_is_fp32_grade(gold):
     assert np.array_equal(netMR.get_preds()[0, 0].cpu().numpy(), exact)
 
 
+@pytest.mark.parametrize('mlp_norm', ['batch', 'no'])
+def test_split_precision_fp16x3_other_norms(mlp_norm):
+    """fp16 x 3 on the BatchNorm and the un-normalised MLP variants (activations up to ~1e2 in the latter): still at fp32
+    rounding level against the exact-fp32 path."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build(mlp_norm=mlp_norm)
+    calib = calib_tensor()
+    pts = seeded_points(5, 2500)
+    netMR.query(pts, calib)
+    exact = netMR.get_preds()[0, 0].cpu().numpy()
+    _lib.call('pifu_set_precision', netMR._ctx.h, 2)
+    try:
+        netMR.query(pts, calib)
+        d = np.abs(netMR.get_preds()[0, 0].cpu().numpy() - exact).max()
+        assert d < (1e-5 if mlp_norm == 'batch' else 3e-5), d
+    finally:
+        _lib.call('pifu_set_precision', netMR._ctx.h, 0)
+
+
 def test_supervised_forward_matches_reference():
     """query(labels=...) + get_error() (forward only) against the reference fixture."""
     import os
