@@ -282,3 +282,42 @@ def test_supervised_forward_matches_reference():
     assert np.allclose([float(CustomBCELoss()(pred, gt, gam, w)), float(CustomBCELoss()(pred, gt, gam))], gold['loss_plain'], rtol=1e-5)
     assert np.allclose([float(CustomBCELoss(brock=True)(pred, gt, gam, w)), float(CustomBCELoss(gamma=0.25)(pred, gt, gam, w))],
                        gold['loss_brock'], rtol=1e-5)
+
+
+def test_default_gemm_is_bit_identical_to_its_predecessors():
+    """k_mlp_gemm_tri (default: one LDS buffer, three blocks per CU), k_mlp_gemm_buf (variant 28) and the pointer-addressed
+    k_mlp_gemm (variant 4) use the same tiles, k order and statistics partials: the occupancy must match bit for bit, on the
+    per-point path and on the column-sharing lattice path."""
+    import ctypes as C
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = golden_nets()
+    calib_t = calib_tensor()
+    calib = np.ascontiguousarray(calib_t[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    res = (C.c_int32 * 3)(20, 24, 56)
+    total = 20 * 24 * 56
+    pts = seeded_points(9, 3210)
+    outs = {}
+    old = os.environ.get('PIFU_GEMM_VARIANT')
+    try:
+        for variant in ('5', '28', '4'):
+            os.environ['PIFU_GEMM_VARIANT'] = variant          # read when the context is created
+            netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+            fc, ff = seeded_features(7)
+            netG.set_features(fc)
+            netMR.set_features(ff)
+            netMR.query(pts, calib_t)
+            q = netMR.get_preds()[0, 0].cpu().numpy().copy()
+            lat = torch.empty(total, device='cuda')
+            _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                      None, 0, total, 700, _lib.Q_FULL_COARSE, _ptr(lat), _stream_ptr(netMR.device))
+            outs[variant] = (q, lat.cpu().numpy())
+    finally:
+        if old is None:
+            os.environ.pop('PIFU_GEMM_VARIANT', None)
+        else:
+            os.environ['PIFU_GEMM_VARIANT'] = old
+    for variant in ('28', '4'):
+        assert np.array_equal(outs['5'][0], outs[variant][0]), variant
+        assert np.array_equal(outs['5'][1], outs[variant][1]), variant
