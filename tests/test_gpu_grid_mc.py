@@ -308,3 +308,44 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     mhz = [100.0 * (b[2 * i] - a[2 * i]) / (b[2 * i + 1] - a[2 * i + 1]) for i in range(8) if a[2 * i + 1] and b[2 * i + 1] > a[2 * i + 1]]
     assert mhz, 'no XCD was sampled by both probes'
     assert all(50.0 < m < 3000.0 for m in mhz), mhz
+
+
+def test_lattice_slabs_at_the_far_end_of_a_1024_cube_grid():
+    """BASELINE configs[4] index range: flat lattice indices close to 2^30.  Two slabs of a 1024^3 lattice (one that ends
+    at the last point with a ragged final chunk, one in the middle that starts inside a column) against the CPU oracle
+    evaluated on the same flat indices."""
+    import ctypes as C
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = mlp_only_nets()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    netMR = nets.PIFuMRNet(of, netG)
+    netG.eval()
+    netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}
+    netG._push_weights()
+    netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}
+    netMR._push_weights()
+    fc, ff = seeded_features(23, hc=128, hf=512)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib_t = calib_tensor()
+    calib = np.ascontiguousarray(calib_t[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    R, chunk = 1024, 5000
+    res = (C.c_int32 * 3)(R, R, R)
+    total = R ** 3
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    for first, count in ((total - 2 * chunk - 1234, 2 * chunk + 1234), (total // 2 + 777, 3 * chunk)):
+        out = torch.empty(count, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  None, first, count, chunk, _lib.Q_FULL_COARSE, _ptr(out), _stream_ptr(netMR.device))
+        got = out.cpu().numpy()
+        with torch.no_grad():
+            for lo in range(0, count, chunk):
+                hi = min(lo + chunk, count)
+                flat = np.arange(first + lo, first + hi, dtype=np.int64)
+                pts = torch.from_numpy(O.grid_points_rect((R, R, R), cinv, flat).astype(np.float32))[None]
+                want = ref.query(pts, calib_t)[0, 0].numpy()
+                assert np.abs(got[lo:hi] - want).max() < 1e-4, (first, lo)
