@@ -264,6 +264,27 @@ def main():
         },
     }
 
+    # ---- the same lattice without the coarse MLP's tail (layers 3-4 + sigmoid produce netG.preds, which nothing on the
+    # gen_mesh path reads: reconstruction() runs this way); reported beside the headline, never as `value`
+    if world == 1 and not args.lean:
+        try:
+            lean_flags = flags & ~_lib.Q_FULL_COARSE
+            pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, lean_flags)
+            fence()
+            l0 = time.perf_counter()
+            for _ in range(args.steps):
+                field_lean = pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, lean_flags)
+            fence()
+            l_el = time.perf_counter() - l0
+            out['without_unread_coarse_tail'] = {
+                'value': round(total * args.steps / l_el / 1e6, 3), 'unit': 'Mqueries/s',
+                'ms_per_step': round(l_el / max(args.steps, 1) * 1e3, 3),
+                'strictly_necessary_flop_per_query': 2784000,
+                'field_identical_to_headline_run': bool(torch.equal(field_lean, field))}
+            log(f"without the unread coarse tail: {out['without_unread_coarse_tail']['value']} Mq/s")
+        except Exception as e:
+            out['without_unread_coarse_tail'] = {'error': repr(e)}
+
     # ---- opt-in split precision on the 16-bit matrix cores (bf16 x 3, fp16 x 3): reported beside the headline, never as `value`
     split_fields = {}
     if world == 1 and not args.no_split_precision:
