@@ -53,6 +53,11 @@ for k in (GEMM, 'k_sample_col', 'k_expand', 'k_last_layer'):
 g = sq.get(GEMM, {})
 if g:
     summary[GEMM + '_sq'] = {c: sum(v) / len(v) for c, v in g.items()}
+    q = summary[GEMM + '_sq']
+    if q.get('GRBM_GUI_ACTIVE') and q.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs: busy share of a SIMD's matrix
+        # pipe while the kernel runs (counts the padded rows' MFMAs too, unlike the algorithmic-FLOP figure of bench.py)
+        q['mfma_pipe_busy_fraction'] = q['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (q['GRBM_GUI_ACTIVE'] / 8.0)
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 0 (the headline lattice and batch '
                      'geometry: per-launch averages over the same launch mix as the timed run)',
            'gemm_kernel': GEMM,
