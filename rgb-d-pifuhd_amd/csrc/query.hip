@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
 // K step costs one more barrier here (the tile is overwritten in place once every wave has read its fragments), which the
 // two other resident blocks cover.  Same tiles, k order and statistics as k_mlp_gemm_buf: bit-identical results.
 // ------------------------------------------------------------------------------------------------
+template <int PRIO>
 __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 {
     constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
         if (more) BUF_GLOAD(step + 1)
         const float *A = lds + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
         const float *B = lds + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        __builtin_amdgcn_s_setprio(3);
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
                 acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __syncthreads();                 // every wave has read its fragments: the tile may be overwritten
         if (more) BUF_LSTORE(0)
         __syncthreads();
@@ -1754,7 +1755,7 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     else if (ctx->gemm_variant == 28)
         hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
     else
-        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
 #else
     if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
         hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
@@ -1764,8 +1765,11 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
         hipLaunchKernelGGL(k_mlp_gemm_wide, dim3((unsigned)round_up(a.ntm, 8) * (a.ntn / 2)), dim3(256), 0, st, a);
     else if (ctx->gemm_variant == 24)
         hipLaunchKernelGGL(k_mlp_gemm_buf<false>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else                                // default: three blocks per CU
-        hipLaunchKernelGGL(k_mlp_gemm_tri, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else if (ctx->gemm_variant == 30)   // the default with its MFMA phase at s_setprio 3 (what the two-block kernels want)
+        hipLaunchKernelGGL(k_mlp_gemm_tri<3>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else                                // default: three blocks per CU, no s_setprio (with three waves per SIMD raising the MFMA
+                                        // phase's priority costs 1.2 %; with two it gains 1-2 %)
+        hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 #endif
 }
 
