@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
 // only when it enters the next segment.  Same tiles, same LDS layout, same MFMA and summation order as
 // k_mlp_gemm<32, 4>: bit-identical results.
 // ------------------------------------------------------------------------------------------------
+#ifndef PIFU_STORE_AUX
+#define PIFU_STORE_AUX 2
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -386,7 +389,8 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    // aux 2 = nt: the layer outputs are streamed (GBs per launch, next read by another kernel), no point in L2 residency
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, PIFU_STORE_AUX);
 }
 
 template <bool PRIO>
