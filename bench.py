@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-genmesh', action='store_true')
+    ap.add_argument('--no-lean-pass', action='store_true', help='skip the extra pass without the unread coarse tail')
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
@@ -204,7 +205,8 @@ def main():
     # both probes sampled; s_memtime counts the clock the CUs actually ran at (power management included)
     mhz = [100.0 * (clk1[2 * x] - clk0[2 * x]) / (clk1[2 * x + 1] - clk0[2 * x + 1])
            for x in range(8) if clk0[2 * x + 1] and clk1[2 * x + 1] > clk0[2 * x + 1]]
-    eff_mhz = sum(mhz) / len(mhz) if mhz else None
+    mhz = sorted(m for m in mhz if 100.0 < m < 4000.0)      # an XCD whose counter was reset by power gating reads garbage: dropped
+    eff_mhz = mhz[len(mhz) // 2] if mhz else None            # median over the XCDs
     _lib.call('pifu_profile_enable', h, 0)
     gemm_ms, gemm_n, gemm_flops = C.c_double(0), C.c_int64(0), C.c_double(0)
     _lib.call('pifu_profile_read', h, C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_flops), 1)
@@ -266,7 +268,7 @@ def main():
 
     # ---- the same lattice without the coarse MLP's tail (layers 3-4 + sigmoid produce netG.preds, which nothing on the
     # gen_mesh path reads: reconstruction() runs this way); reported beside the headline, never as `value`
-    if world == 1 and not args.lean:
+    if world == 1 and not args.lean and not args.no_lean_pass:
         try:
             lean_flags = flags & ~_lib.Q_FULL_COARSE
             pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, lean_flags)

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/kprof
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps 2 --warmup 1 --features ${FEATURES:-synthetic} --no-cpu-baseline --no-genmesh --no-split-precision > $OUT/line.json 2> $OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps 2 --warmup 1 --features ${FEATURES:-synthetic} --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass > $OUT/line.json 2> $OUT/err.log
 python - <<'P'
 import csv, glob
 f = glob.glob('gpurun_out/kprof/*/*_kernel_stats.csv')[0]

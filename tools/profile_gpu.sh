@@ -5,10 +5,10 @@ set -x
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-genmesh --no-split-precision"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 # same lattice and batch geometry as the headline run, so per-launch averages are over the same launch mix
-SMALL="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-genmesh --no-split-precision"
+SMALL="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $SMALL > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $SMALL > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $SMALL > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err
