@@ -181,6 +181,9 @@ struct Vol {
     int c0, c1, c2;            // cells per axis
     int64_t ncells;
     double level;
+    // 8 x 8 x 8-cell bricks whose 9 x 9 x 9 nodes are not all on one side of the level (k_mc_bricks); null = classify every cell
+    const uint8_t *brick;
+    int b0, b1, b2;
 };
 
 __device__ __forceinline__ double vol_at(const Vol &v, int z, int y, int x)
@@ -203,6 +206,11 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
     ci.x = (int)(cell % v.c2);
     ci.y = (int)((cell / v.c2) % v.c1);
     ci.z = (int)(cell / ((int64_t)v.c2 * v.c1));
+    ci.nt = 0;
+    ci.nown = 0;
+    ci.row = nullptr;
+    // a cell of a brick whose nodes all lie on one side of the level has index 0 or 255: nothing to load
+    if (v.brick && !v.brick[((size_t)(ci.z >> 3) * v.b1 + (ci.y >> 3)) * v.b2 + (ci.x >> 3)]) return false;
     int index = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -258,6 +266,28 @@ __global__ void k_mc_minmax_final(const float *part, int n, float *out)
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
     if (threadIdx.x == 0) { out[0] = lo; out[1] = hi; }
+}
+
+// pass 0: one wave per 8 x 8 x 8-cell brick: does the sign of (value - level) - evaluated exactly as classify() does -
+// change anywhere among its 9 x 9 x 9 nodes?  ~96 % of the cells of a body at 512^3 sit in bricks where it does not; the
+// three classification passes then skip them without touching the volume.
+__global__ void k_mc_bricks(const Vol v, uint8_t *brick)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t nb = (int64_t)v.b0 * v.b1 * v.b2;
+    if (b >= nb) return;
+    const int bx = (int)(b % v.b2), by = (int)((b / v.b2) % v.b1), bz = (int)(b / ((int64_t)v.b2 * v.b1));
+    bool pos = false, neg = false;
+    for (int i = lane; i < 729; i += 64) {
+        const int dz = i / 81, dy = (i / 9) % 9, dx = i % 9;
+        const int z = min(bz * 8 + dz, v.n0 - 1), y = min(by * 8 + dy, v.n1 - 1), x = min(bx * 8 + dx, v.n2 - 1);
+        const bool p = (vol_at(v, z, y, x) - v.level) > 0;
+        pos |= p;
+        neg |= !p;
+    }
+    const bool any_pos = __builtin_amdgcn_ballot_w64(pos) != 0ull, any_neg = __builtin_amdgcn_ballot_w64(neg) != 0ull;
+    if (lane == 0) brick[b] = (any_pos && any_neg) ? 1 : 0;
 }
 
 // pass 1: block b covers cells [256 b, 256 b + 256) of the serial scan
@@ -388,20 +418,26 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->mc.valid = false;
-    Vol v{volume, dtype, n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1), level};
+    Vol v{volume, dtype, n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1), level, nullptr,
+          (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8};
     const int64_t nblocks = (v.ncells + 255) / 256;
     const int mm_blocks = 1024;
-    // arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][edge_index 3*N int32]
+    // arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][brick map][edge_index 3*N int32]
     const size_t scan_bytes = (size_t)round_up((nblocks + 1) * 8, 256);
     const size_t mm_bytes = (size_t)round_up((2 * mm_blocks + 2) * 4, 256);
+    const int64_t nbricks = (int64_t)v.b0 * v.b1 * v.b2;
+    const size_t brick_bytes = (size_t)round_up(nbricks, 256);
     const size_t edge_bytes = (size_t)3 * n0 * n1 * n2 * sizeof(int32_t);
-    int rc = pifu_ensure(ctx->mc_arena, 2 * scan_bytes + 256 + mm_bytes + edge_bytes);
+    int rc = pifu_ensure(ctx->mc_arena, 2 * scan_bytes + 256 + mm_bytes + brick_bytes + edge_bytes);
     if (rc) return rc;
     char *base = (char *)ctx->mc_arena.p;
     uint64_t *blk_verts = (uint64_t *)base;
     uint64_t *blk_tris = (uint64_t *)(base + scan_bytes);
     uint64_t *totals = (uint64_t *)(base + 2 * scan_bytes);
     float *mm = (float *)(base + 2 * scan_bytes + 256);
+    uint8_t *brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    hipLaunchKernelGGL(k_mc_bricks, dim3((unsigned)((nbricks + 3) / 4)), dim3(256), 0, st, v, brick);
+    v.brick = brick;
 
     hipLaunchKernelGGL(k_mc_minmax, dim3(mm_blocks), dim3(256), 0, st, v, mm + 2);
     hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(mm + 2), mm_blocks, mm);
@@ -439,14 +475,17 @@ extern "C" int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_st
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const McState &m = ctx->mc;
-    Vol v{m.volume, m.dtype, m.n0, m.n1, m.n2, m.n0 - 1, m.n1 - 1, m.n2 - 1, (int64_t)(m.n0 - 1) * (m.n1 - 1) * (m.n2 - 1), m.level};
+    Vol v{m.volume, m.dtype, m.n0, m.n1, m.n2, m.n0 - 1, m.n1 - 1, m.n2 - 1, (int64_t)(m.n0 - 1) * (m.n1 - 1) * (m.n2 - 1), m.level,
+          nullptr, (m.n0 - 1 + 7) / 8, (m.n1 - 1 + 7) / 8, (m.n2 - 1 + 7) / 8};
     const int64_t nblocks = (v.ncells + 255) / 256;
     const size_t scan_bytes = (size_t)round_up((nblocks + 1) * 8, 256);
     const size_t mm_bytes = (size_t)round_up((2 * 1024 + 2) * 4, 256);
+    const size_t brick_bytes = (size_t)round_up((int64_t)v.b0 * v.b1 * v.b2, 256);
     char *base = (char *)ctx->mc_arena.p;
     uint64_t *blk_verts = (uint64_t *)base;
     uint64_t *blk_tris = (uint64_t *)(base + scan_bytes);
-    int32_t *edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    v.brick = (const uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);      // built by pifu_mc_count for this volume
+    int32_t *edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + brick_bytes);
     hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts, verts, edge_index);
     hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts,
                        (const uint64_t *)blk_tris, (const int32_t *)edge_index, faces);
