@@ -42,9 +42,12 @@ def pmc(dirname):
 fetch, write, sq = pmc('pmc_fetch'), pmc('pmc_write'), pmc('pmc_sq')
 summary = {}
 GEMM = next((k for k in ('k_mlp_gemm_tri', 'k_mlp_gemm_buf') if k in fetch), 'k_mlp_gemm')
-for k in (GEMM, 'k_sample_col', 'k_expand', 'k_last_layer'):
+for k in (GEMM, 'k_walk', 'k_sample_col', 'k_seg_prepare', 'k_last_layer'):
     f = fetch.get(k, {}).get('FETCH_SIZE', [])
     w = write.get(k, {}).get('WRITE_SIZE', [])
+    if k != GEMM and f and w:      # small set-up launches would dilute the per-launch figure of the batch-sized ones
+        f = [x for x in f if x > 0.5 * max(f)]
+        w = [x for x in w if x > 0.5 * max(w)]
     if f and w:
         fb = 2.0 * 1024.0 * sum(f) / len(f)      # KiB -> bytes, x2 gfx950 correction
         wb = 1024.0 * sum(w) / len(w)
