@@ -65,10 +65,12 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
+#ifdef PIFU_LAB     // tools/lab builds only: kernel selection and diagnostics through the environment
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
     if (const char *v = getenv("PIFU_COLUMN_MODE")) c->col_enable = atoi(v);
     if (const char *v = getenv("PIFU_DEPTH_WALK")) c->walk_enable = atoi(v);
     if (const char *v = getenv("PIFU_PRECISION")) c->precision = atoi(v);
+#endif
     if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         pifu_set_error("pinned host allocation failed");
@@ -85,12 +87,15 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
             return PIFU_ERR_HIP;
         }
     }
+#ifdef PIFU_LAB
     if (c->gemm_variant == 9 || getenv("PIFU_DEBUG_STAMPS")) { (void)hipMalloc(&c->debug_buf, (64 * 40 * 4 + 16384 * 16) * 8); (void)hipMemset(c->debug_buf, 0, (64 * 40 * 4 + 16384 * 16) * 8); }
+#endif
     *out = c;
     return PIFU_OK;
 }
 
-// diagnostics only (not part of the public ABI): copy the stamp buffer of the SCHED == 2 build to the host
+#ifdef PIFU_LAB
+// tools/lab builds only (not part of the ABI): copy the in-kernel stamp buffer of the diagnostic kernels to the host
 extern "C" int pifu_debug_read(pifu_ctx *ctx, void *host, size_t bytes)
 {
     if (!ctx || !ctx->debug_buf) return PIFU_ERR_STATE;
@@ -98,10 +103,11 @@ extern "C" int pifu_debug_read(pifu_ctx *ctx, void *host, size_t bytes)
     PIFU_HIP(hipMemcpy(host, ctx->debug_buf, bytes, hipMemcpyDeviceToHost));
     return PIFU_OK;
 }
+#endif
 
 static void free_layer(MlpLayer &l)
 {
-    float **ptrs[] = {&l.w, &l.bias, &l.gamma, &l.beta, &l.fixed_scale, &l.fixed_shift, &l.w_col, &l.wz};
+    float **ptrs[] = {&l.w, &l.bias, &l.gamma, &l.beta, &l.fixed_scale, &l.fixed_shift, &l.w_col, &l.w_colT, &l.wz};
     for (float **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -129,9 +135,11 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+#ifdef PIFU_LAB
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
-    if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
     if (ctx->debug_buf) (void)hipFree(ctx->debug_buf);
+#endif
+    if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
     delete ctx;
@@ -317,9 +325,16 @@ inline char *put_uint(char *o, uint64_t v)
     return o;
 }
 
+constexpr int SLOW_CHARS = 320;     // "%.4f" of the largest finite double: 1 sign + 309 digits + 5 = 315 characters
+
 inline char *put_fixed4(char *o, double x)
 {
-    if (!(fabs(x) < 1e11)) return o + sprintf(o, "%.4f", x);       // huge / inf / nan: defer to libc
+    if (!(fabs(x) < 1e11)) {                                       // huge / inf / nan (the caller budgets SLOW_CHARS for each)
+        if (x != x) { memcpy(o, "nan", 3); return o + 3; }         // Python prints nan without a sign
+        if (fabs(x) == INFINITY) { const char *t = x < 0 ? "-inf" : "inf"; const size_t n = strlen(t); memcpy(o, t, n); return o + n; }
+        const int n = snprintf(o, SLOW_CHARS, "%.4f", x);
+        return o + (n < SLOW_CHARS ? n : SLOW_CHARS - 1);
+    }
     if (signbit(x)) *o++ = '-';
     const double ax = fabs(x);
     const double p = ax * 1e4;
@@ -363,7 +378,10 @@ extern "C" int pifu_write_obj(const char *path, const double *verts, const doubl
             const int64_t lo = t * per, hi = std::min(total, lo + per);
             if (lo >= hi) return;
             const int64_t nv_here = std::max<int64_t>(0, std::min(hi, nverts) - lo), nf_here = (hi - lo) - nv_here;
-            out[t].reset(new char[(size_t)nv_here * 168 + (size_t)nf_here * 40 + 64]);    // uninitialised on purpose
+            size_t slow = 0;      // values outside the fast formatter's range need up to SLOW_CHARS characters each
+            for (int64_t i = lo; i < lo + nv_here; ++i)
+                for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
+            out[t].reset(new char[(size_t)nv_here * 168 + (size_t)nf_here * 40 + slow * SLOW_CHARS + 64]);    // uninitialised on purpose
             char *const base = out[t].get();
             char *o = base;
             for (int64_t i = lo; i < hi; ++i) {

@@ -957,11 +957,20 @@ extern "C" int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *
     for (int i = 0; i < rank; ++i) { hp.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
     hp.data.assign(host, host + n);
     S.params[name] = std::move(hp);
-    // drop every packed copy derived from this parameter
+    // drop every packed copy derived from this parameter: keys `<name>...` (packed weights / biases) and keys
+    // `<module>#...` derived from several tensors of the owning module (folded eval-mode BatchNorm `<module>#bn_eval.s/.b`
+    // from weight / bias / running_mean / running_var; the repacked 7x7 output conv `<module>#w7`)
     const std::string nm(name);
+    const size_t dot = nm.rfind('.');
+    const std::string mod = dot == std::string::npos ? std::string() : nm.substr(0, dot) + "#";
+    bool dropped = false;
     for (auto it = S.dev.begin(); it != S.dev.end();) {
-        if (it->first.compare(0, nm.size(), nm) == 0) { (void)hipFree(it->second); it = S.dev.erase(it); }
-        else ++it;
+        const bool hit = it->first.compare(0, nm.size(), nm) == 0 || (!mod.empty() && it->first.compare(0, mod.size(), mod) == 0);
+        if (hit) {
+            if (!dropped) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); dropped = true; }   // a filter may still be reading it
+            (void)hipFree(it->second);
+            it = S.dev.erase(it);
+        } else ++it;
     }
     return PIFU_OK;
 }

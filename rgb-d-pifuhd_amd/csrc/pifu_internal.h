@@ -110,22 +110,24 @@ struct pifu_ctx {
     // column tables of the lattice evaluation (column sharing)
     DevBuf col_arena;
     int col_enable = 1;
-    int walk_enable = 1;                  // depth walk of coarse layer 1 on lattice sources (env PIFU_DEPTH_WALK)
+    int walk_enable = 1;                  // depth walk of coarse layer 1 on lattice sources
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
     float *ident_scale = nullptr, *ident_shift = nullptr;   // device ones / zeros [PIFU_MAX_WIDTH]
     // optional per-launch timing of the dominant kernel (k_mlp_gemm) with HIP events on the launch stream
     int num_cus = 256;
-    void *debug_buf = nullptr;            // diagnostics only
+#ifdef PIFU_LAB     // tools/lab builds only
+    void *debug_buf = nullptr;            // in-kernel stamp buffer of the diagnostic kernels
     void *tile_ctr = nullptr;             // k_mlp_gemm_dyn work-queue counters: ring of [8] int slots
     int tile_ctr_next = 0;
+    int gemm_variant = 5;                 // kernel / schedule selection (env PIFU_GEMM_VARIANT)
+#endif
     void *clock_buf = nullptr;            // pifu_clock_probe: [8 XCDs][shader ticks, real-time ticks]
     // arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default), 1 = bf16 x 3 split precision on the bf16 matrix cores
     int precision = 0;
     struct Planes { void *hi; void *lo; size_t n; };
     std::map<const void *, Planes> bf16_planes;
-    int gemm_variant = 5;                 // schedule variant of k_mlp_gemm (env PIFU_GEMM_VARIANT; tuning aid)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
     size_t prof_used = 0;                 // events in use

@@ -15,7 +15,7 @@
 //   row tile never straddles two chunks; padded rows carry zero features and are masked out of the
 //   statistics.
 //
-// The dominant kernel is k_mlp_gemm_tri (k_mlp_gemm_buf and k_mlp_gemm are its predecessors, kept for A/B): exact-fp32
+// The dominant kernel is k_mlp_gemm_tri (its predecessors k_mlp_gemm_buf / k_mlp_gemm live in tools/lab): exact-fp32
 // MFMA (v_mfma_f32_32x32x2_f32), 128x128x32 block tile, 4 waves each owning a 64x64 output tile (2x2 MFMA tiles, 64
 // accumulator VGPRs), register-staged LDS (one 36 KB buffer, three blocks per CU) with the norm+LeakyReLU prologue
 // fused into the staging pass, per-column (sum, sum^2) partials for the next norm fused into the epilogue
@@ -61,7 +61,11 @@ struct GemmArgs {
     float2 *partial;  // [ntm][ldy] (sum, sum of squares) over the valid rows of the tile, or null
     int ntm, ntn;
     ChunkGeom g;
-    unsigned long long *stamps;   // diagnostic builds only (SCHED == 2): [64 blocks][40 steps][4]
+#ifdef PIFU_LAB
+    unsigned long long *stamps;   // diagnostic kernels only: [64 blocks][40 steps][4] s_memtime stamps
+    int *tile_ctr;   // k_mlp_gemm_dyn: 8 work-queue counters (one per XCD label), zero at launch
+    int dbg;   // EXPERIMENTS builds: bit0 skip Y stores, bit1 skip statistics, bit2 skip column init, bit3 skip MFMAs
+#endif
     // column sharing (lattice sources): the accumulators start from the per-(i,j)-column product of the skip
     // input's image-feature part, Q[colidx[row]][qoff + c] + wz[c] * zf[row], instead of zero
     const float *colQ;    // [ncols][ldq] or null
@@ -69,7 +73,7 @@ struct GemmArgs {
     const float *colwz;   // [cout_pad] weight of the depth feature, or null
     const float *zf;      // [rows] depth feature per point row
     const int *colidx;    // [rows] column of the point row
-    // per-K-step operand descriptors (k_mlp_gemm_v2): everything that depends on the segment is resolved on the
+    // per-K-step operand descriptors (k_mlp_gemm_split): everything that depends on the segment is resolved on the
     // host, so the kernel fetches one descriptor per step with scalar loads instead of a ~60-instruction select chain
     struct StepDesc {
         const float *ptr;     // segment base + k offset inside the segment (row 0)
@@ -81,11 +85,9 @@ struct GemmArgs {
         int pad;
     } steps[40];
     int nsteps;
-    int *tile_ctr;   // k_mlp_gemm_dyn: 8 work-queue counters (one per XCD label), zero at launch
-    int dbg;   // EXPERIMENTS builds: bit0 skip Y stores, bit1 skip statistics, bit2 skip column init, bit3 skip MFMAs
 };
 
-#ifdef PIFU_GEMM_EXPERIMENTS
+#if defined(PIFU_LAB) && defined(PIFU_GEMM_EXPERIMENTS)
 #define PIFU_DBG(a_) ((a_).dbg)
 #else
 #define PIFU_DBG(a_) 0
@@ -96,277 +98,12 @@ __device__ __forceinline__ int chunk_len(const ChunkGeom &g, int c) { return c =
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 
 // ------------------------------------------------------------------------------------------------
-// k_mlp_gemm:  Y[rows][Cout] = act(A)[rows][K] * W^T + bias,  A = concatenation of <= 3 segments.
-// Template: TBK = K step (16 or 32), SCHED = 0 (staging after the step's MFMAs) or 1 (staging of the next
-// tile interleaved between the MFMA groups of the current one, so a wave has no MFMA-free phase).
-// ------------------------------------------------------------------------------------------------
-template <int TBK, int SCHED>
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm(const GemmArgs a)
-{
-    constexpr int LD = TBK + 4;              // row stride (floats): 144 B / 80 B, conflict-free ds_read_b128
-    constexpr int TILE = BM * LD;            // one operand tile
-    constexpr int F4_PER_ROW = TBK / 4;      // float4 columns per tile row
-    constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
-    constexpr int NP = BM / ROWS_PER_PASS;   // staging passes per operand (4 at BK 32, 2 at BK 16)
-    constexpr int NS = TBK / 8;              // MFMA groups of 8 k per step
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // [buf][A|B]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so all column tiles of
-    // one row tile get the same (b % 8) label and consecutive slots -> the A row tile is re-read from that
-    // XCD's L2, not from HBM.  Pure speed choice; correctness does not depend on placement.
-    // SCHED == 5: persistent blocks (grid = 2 x CUs) walk the tile list; otherwise one tile per block
-    const int nq_all = ((a.ntm + 7) / 8) * 8 * a.ntn;
-  for (int q_tile = blockIdx.x; q_tile < (SCHED == 5 ? nq_all : (int)blockIdx.x + 1); q_tile += gridDim.x) {
-    const int xcd = q_tile & 7, slot = q_tile >> 3;
-    const int tile_n = slot % a.ntn;
-    const int tile_m = (slot / a.ntn) * 8 + xcd;
-    if (tile_m >= a.ntm) continue;
-    const int chunk_id = tile_m / a.g.tpc;
-    const size_t row0 = (size_t)tile_m * BM;
-    const int col0 = tile_n * BN;
-
-    const int kq = tid % F4_PER_ROW, sr = tid / F4_PER_ROW;   // staging: float4 column kq of rows sr + p * ROWS_PER_PASS
-    const int b1 = a.seg[0].width;
-    const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
-    const int nsteps = a.ldw / TBK;
-
-    // One K step of both operands in flight in registers.  The per-segment choices are made with scalar
-    // selects so the staging code is branch-free: raw segments use scale 1 / shift 0 / slope 1.
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;      // (named registers: arrays here end up in scratch)
-    ra2 = ra3 = rw2 = rw3 = make_float4(0, 0, 0, 0);
-    float rslope = 1.f;
-
-#define PIFU_GLOAD(step_)                                                                                  \
-    {                                                                                                      \
-        const int kk = (step_) * TBK;                                                                      \
-        const int sg = (kk >= b1) + (kk >= b2);                                                            \
-        const float *ptr = sg == 0 ? a.seg[0].ptr : (sg == 1 ? a.seg[1].ptr : a.seg[2].ptr);               \
-        const float *sc = sg == 0 ? a.seg[0].scale : (sg == 1 ? a.seg[1].scale : a.seg[2].scale);          \
-        const float *sh = sg == 0 ? a.seg[0].shift : (sg == 1 ? a.seg[1].shift : a.seg[2].shift);          \
-        const int ld = sg == 0 ? a.seg[0].ld : (sg == 1 ? a.seg[1].ld : a.seg[2].ld);                      \
-        const int sld = sg == 0 ? a.seg[0].sld : (sg == 1 ? a.seg[1].sld : a.seg[2].sld);                  \
-        const int md = sg == 0 ? a.seg[0].mode : (sg == 1 ? a.seg[1].mode : a.seg[2].mode);                \
-        rslope = md == 0 ? 1.f : 0.01f;                                                                    \
-        const int kl = kk - (sg == 0 ? 0 : (sg == 1 ? b1 : b2)) + kq * 4;                                  \
-        const float *ap = ptr + (row0 + sr) * (size_t)ld + kl;                                             \
-        ra0 = *reinterpret_cast<const float4 *>(ap);                                                       \
-        ra1 = *reinterpret_cast<const float4 *>(ap + (size_t)ROWS_PER_PASS * ld);                          \
-        if constexpr (NP > 2) {                                                                            \
-            ra2 = *reinterpret_cast<const float4 *>(ap + (size_t)2 * ROWS_PER_PASS * ld);                  \
-            ra3 = *reinterpret_cast<const float4 *>(ap + (size_t)3 * ROWS_PER_PASS * ld);                  \
-        }                                                                                                  \
-        rsc = *reinterpret_cast<const float4 *>(sc + (size_t)chunk_id * sld + kl);                         \
-        rsh = *reinterpret_cast<const float4 *>(sh + (size_t)chunk_id * sld + kl);                         \
-        const float *wp = a.W + (size_t)(col0 + sr) * a.ldw + kk + kq * 4;                                 \
-        rw0 = *reinterpret_cast<const float4 *>(wp);                                                       \
-        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)ROWS_PER_PASS * a.ldw);                       \
-        if constexpr (NP > 2) {                                                                            \
-            rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)2 * ROWS_PER_PASS * a.ldw);               \
-            rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)3 * ROWS_PER_PASS * a.ldw);               \
-        }                                                                                                  \
-    }
-
-#define PIFU_STORE1(buf_, p_, va_, vw_)                                                                    \
-    {                                                                                                      \
-        float *la = lds + (buf_) * 2 * TILE + (sr + (p_) * ROWS_PER_PASS) * LD + kq * 4;                   \
-        float t_;                                                                                          \
-        t_ = fmaf(va_.x, rsc.x, rsh.x); va_.x = fmaxf(t_, rslope * t_);                                    \
-        t_ = fmaf(va_.y, rsc.y, rsh.y); va_.y = fmaxf(t_, rslope * t_);                                    \
-        t_ = fmaf(va_.z, rsc.z, rsh.z); va_.z = fmaxf(t_, rslope * t_);                                    \
-        t_ = fmaf(va_.w, rsc.w, rsh.w); va_.w = fmaxf(t_, rslope * t_);                                    \
-        *reinterpret_cast<float4 *>(la) = va_;                                                             \
-        *reinterpret_cast<float4 *>(la + TILE) = vw_;                                                      \
-    }
-    // first / second half of the staging passes
-#define PIFU_LSTORE_H0(buf_)                                                                               \
-    {                                                                                                      \
-        PIFU_STORE1(buf_, 0, ra0, rw0)                                                                     \
-        if constexpr (NP > 2) PIFU_STORE1(buf_, 1, ra1, rw1)                                               \
-    }
-#define PIFU_LSTORE_H1(buf_)                                                                               \
-    {                                                                                                      \
-        if constexpr (NP > 2) {                                                                            \
-            PIFU_STORE1(buf_, 2, ra2, rw2)                                                                 \
-            PIFU_STORE1(buf_, 3, ra3, rw3)                                                                 \
-        } else {                                                                                           \
-            PIFU_STORE1(buf_, 1, ra1, rw1)                                                                 \
-        }                                                                                                  \
-    }
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    if (a.colQ && !(PIFU_DBG(a) & 4)) {   // column sharing: start from the per-column product (gathered while the first tile loads are in flight)
-        const int hh = lane >> 5, jj = lane & 31;
-        const int c0 = col0 + wn * 64 + jj, c1 = c0 + 32;
-        const float wz0 = a.colwz ? a.colwz[c0] : 0.f, wz1 = a.colwz ? a.colwz[c1] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const size_t rowA = row0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh, rowB = rowA + 32;
-            const int ciA = a.colidx[rowA], ciB = a.colidx[rowB];
-            const float zA = a.zf[rowA], zB = a.zf[rowB];
-            const float *qA = a.colQ + (size_t)ciA * a.ldq + a.qoff, *qB = a.colQ + (size_t)ciB * a.ldq + a.qoff;
-            acc00[r] = fmaf(wz0, zA, qA[c0]);
-            acc01[r] = fmaf(wz1, zA, qA[c1]);
-            acc10[r] = fmaf(wz0, zB, qB[c0]);
-            acc11[r] = fmaf(wz1, zB, qB[c1]);
-        }
-    }
-    // lane (i = lane & 31, h = lane >> 5) reads k = 8 s + 4 h + t, t = 0..3, for both operands
-    auto mfma_group = [&](const float *A, const float *B, int s) __attribute__((always_inline)) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
-        const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
-        const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
-        const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
-        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
-        }
-    };
-
-    unsigned long long t_begin = 0;
-    if (SCHED == 2) t_begin = __builtin_amdgcn_s_memtime();
-    PIFU_GLOAD(0)
-    PIFU_LSTORE_H0(0)
-    PIFU_LSTORE_H1(0)
-    __syncthreads();
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) PIFU_GLOAD(step + 1)
-        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        if (SCHED == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
-            if (more) {
-                PIFU_LSTORE_H0(buf ^ 1)
-                PIFU_LSTORE_H1(buf ^ 1)
-            }
-        } else if (SCHED == 3) {     // non-MFMA section (staging, barrier, next loads) at raised priority
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
-            __builtin_amdgcn_s_setprio(3);
-            if (more) {
-                PIFU_LSTORE_H0(buf ^ 1)
-                PIFU_LSTORE_H1(buf ^ 1)
-            }
-        } else if (SCHED == 4 || SCHED == 5) {     // MFMA phase at raised priority
-            __builtin_amdgcn_s_setprio(3);
-            if (!(PIFU_DBG(a) & 8))
-#pragma unroll
-            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
-            __builtin_amdgcn_s_setprio(0);
-            if (more) {
-                PIFU_LSTORE_H0(buf ^ 1)
-                PIFU_LSTORE_H1(buf ^ 1)
-            }
-        } else if (SCHED == 2) {     // diagnostic: s_memtime stamps of one wave per block (never the product path)
-            const bool rec = a.stamps && blockIdx.x < 64 && step < 40 && tid == 0;
-            unsigned long long t0, t1, t2;
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) mfma_group(A, B, s);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                PIFU_LSTORE_H0(buf ^ 1)
-                PIFU_LSTORE_H1(buf ^ 1)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (rec) {
-                unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 40 + step) * 4;
-                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
-            }
-        } else {
-            // the other LDS buffer is free during the whole step (its readers finished before the last
-            // barrier), so the next tile is written in two halves between this step's MFMA groups
-            constexpr int H = NS / 2;
-#pragma unroll
-            for (int s = 0; s < H; ++s) mfma_group(A, B, s);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) PIFU_LSTORE_H0(buf ^ 1)
-#pragma unroll
-            for (int s = H; s < NS - (NS > 2 ? 1 : 0); ++s) mfma_group(A, B, s);
-            if (more) PIFU_LSTORE_H1(buf ^ 1)
-            if (NS > 2) mfma_group(A, B, NS - 1);
-        }
-        __syncthreads();
-    }
-
-    if (SCHED == 2 && a.stamps && lane == 0 && blockIdx.x < 16384) {
-        unsigned long long *o = a.stamps + 64 * 40 * 4 + ((size_t)blockIdx.x * 4 + wave) * 4;
-        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_getreg(63492); o[3] = __builtin_amdgcn_s_getreg(63508);
-    }
-    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows.  Addresses are a uniform
-    // (scalar) tile base + a per-lane 32-bit byte offset, so the 64 stores per lane need no vector address arithmetic
-    // (every VALU instruction here is time the partner wave's fp32 MFMA stream does not get).
-    const int h = lane >> 5, j = lane & 31;
-    const int local0 = (tile_m % a.g.tpc) * BM;
-    int nvalid = chunk_len(a.g, chunk_id) - local0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-    float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
-    char *ytile = reinterpret_cast<char *>(a.Y + row0 * (size_t)a.ldy + col0);                     // uniform
-    const unsigned ldy4 = (unsigned)a.ldy * 4u;
-    const unsigned voff = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;       // per lane
-    const bool full = nvalid >= BM;
-
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float bias = a.bias[col0 + wn * 64 + nt * 32 + j];
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = mt * 32 + (r & 3) + 8 * (r >> 2);                                  // uniform part of the row
-                const float v = acc[r] + bias;
-                if (!(PIFU_DBG(a) & 1))
-                    *reinterpret_cast<float *>(ytile + ((size_t)rr * ldy4 + nt * 128) + voff) = v;
-                if (full) { s += v; q = fmaf(v, v, q); }
-                else if (wm * 64 + rr + 4 * h < nvalid) { s += v; q = fmaf(v, v, q); }
-            }
-        }
-        if (a.partial) {
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (lane < 32) {
-                red[(0 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = s;
-                red[(1 * 2 + wm) * BN + wn * 64 + nt * 32 + j] = q;
-            }
-        }
-    }
-    if (a.partial) {
-        __syncthreads();
-        if (tid < BN)
-            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
-                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
-    }
-    if (SCHED == 5) __syncthreads();     // the next tile's prologue overwrites the LDS scratch used above
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_buf: k_mlp_gemm<32, 4> with buffer addressing.  On gfx950 the fp32 MFMA shares the vector ALUs, so every
-// VALU instruction of the staging path, the column-init gather and the epilogue is matrix time lost.  All global
-// accesses here are `buffer_load/store ... s[rsrc], soffset offen`: a uniform (SGPR) tile descriptor + a per-lane 32-bit
-// byte offset + a scalar offset, so no 64-bit vector address arithmetic is left; the norm + LeakyReLU transform runs on
-// packed fp32 (v_pk_fma_f32 / v_pk_mul_f32), and the operand segment of a K step comes from a cursor that is re-resolved
-// only when it enters the next segment.  Same tiles, same LDS layout, same MFMA and summation order as
-// k_mlp_gemm<32, 4>: bit-identical results.
+// Buffer addressing.  On gfx950 the fp32 MFMA shares the vector ALUs, so every VALU instruction of the staging path, the
+// column-init gather and the epilogue is matrix time lost.  All global accesses of the GEMM are
+// `buffer_load/store ... s[rsrc], soffset offen`: a uniform (SGPR) tile descriptor + a per-lane 32-bit byte offset + a
+// scalar offset, so no 64-bit vector address arithmetic is left; the norm + LeakyReLU transform runs on packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32), and the operand segment of a K step comes from a cursor that is re-resolved only when it
+// enters the next segment.
 // ------------------------------------------------------------------------------------------------
 #ifndef PIFU_STORE_AUX
 #define PIFU_STORE_AUX 2
@@ -393,46 +130,8 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, PIFU_STORE_AUX);
 }
 
-template <bool PRIO>
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
-{
-    constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];   // [buf][A|B]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int q_tile = blockIdx.x;
-    const int xcd = q_tile & 7, slot = q_tile >> 3;
-    const int tile_n = slot % a.ntn;
-    const int tile_m = (slot / a.ntn) * 8 + xcd;
-    if (tile_m >= a.ntm) return;
-    const int chunk_id = tile_m / a.g.tpc;
-    const size_t row0 = (size_t)tile_m * BM;
-    const int col0 = tile_n * BN;
-    // EXPERIMENTS builds (PIFU_GEMM_DBG): bit 16 = every block LOADS tile (0, 0) (memory system out of the picture)
-    const size_t row0_ld = (PIFU_DBG(a) & 16) ? 0 : row0;
-    const int col0_ld = (PIFU_DBG(a) & 16) ? 0 : col0;
-
-    const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
-    const unsigned kb = kq * 16;
-    const int nsteps = a.ldw / TBK;
-    const unsigned ldw4 = (unsigned)a.ldw * 4u;
-    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0_ld * a.ldw);
-    const unsigned voW = (unsigned)sr * ldw4 + kb;
-
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
-    float rslope = 1.f;
-
-    // cursor of the next K step to fetch: every per-segment quantity is resolved when the cursor ENTERS a segment (a rare
-    // uniform branch), so a step costs a handful of scalar adds instead of a ~70-instruction select chain
-    int c_seg = 0, c_left = a.seg[0].width / TBK;
-    unsigned c_ks4 = 0, c_kw4 = 0;
-    unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
-    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0_ld * (size_t)a.seg[0].ld);
-    __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
-    __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
-    float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
-    unsigned voA = (unsigned)sr * c_ld4 + kb;
+// Staging / epilogue macros shared by k_mlp_gemm_tri and (lab builds) its predecessors.  They expect the locals of the
+// kernel body: rW, voW, ldw4, kb, sr, kq, row0_ld, chunk_id, the segment cursor c_*, ra0-3 / rw0-3 / rsc / rsh / rslope.
 #define BUF_GLOAD(step_)                                                                                   \
     {                                                                                                      \
         rslope = c_slope;                                                                                  \
@@ -490,69 +189,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
         *reinterpret_cast<float4 *>(la + TILE + 64 * LD) = rw2;                                            \
         *reinterpret_cast<float4 *>(la + TILE + 96 * LD) = rw3;                                            \
     }
-
-    const int h = lane >> 5, j = lane & 31;
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    BUF_GLOAD(0)
-    if (a.colQ && !(PIFU_DBG(a) & 4)) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
-        const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
-        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);     // descriptors stay block-uniform (SGPRs)
-        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
-        const float wz0 = a.colwz ? a.colwz[col0 + wn * 64 + j] : 0.f, wz1 = a.colwz ? a.colwz[col0 + wn * 64 + 32 + j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
-            const unsigned ciA = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so, 0);
-            const unsigned ciB = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so + 128u, 0);
-            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
-            const unsigned qA = ciA * ldq4 + (unsigned)(wn * 64 + j) * 4u, qB = ciB * ldq4 + (unsigned)(wn * 64 + j) * 4u;
-            acc00[r] = fmaf(wz0, zA, buf_load1(rQ, qA, 0));
-            acc01[r] = fmaf(wz1, zA, buf_load1(rQ, qA, 128));
-            acc10[r] = fmaf(wz0, zB, buf_load1(rQ, qB, 0));
-            acc11[r] = fmaf(wz1, zB, buf_load1(rQ, qB, 128));
-        }
-    }
-    BUF_LSTORE(0)
-    __syncthreads();
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) BUF_GLOAD(step + 1)
-        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
-            const float4 b1v = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
-            }
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (more) BUF_LSTORE(buf ^ 1)
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
-    const int local0 = (tile_m % a.g.tpc) * BM;
-    int nvalid = chunk_len(a.g, chunk_id) - local0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-    float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
-    const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
-    const unsigned ldy4 = (unsigned)a.ldy * 4u;
-    const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;
-    const float bias0 = a.bias[col0 + wn * 64 + j], bias1 = a.bias[col0 + wn * 64 + 32 + j];
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #define BUF_EPI(acc_, mt_, nt_, bias_, s_, q_, CHECK_)                                                     \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
         const int rr = (mt_) * 32 + (r & 3) + 8 * (r >> 2);                                                \
@@ -560,28 +196,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_buf(const GemmArgs a)
         if (!(PIFU_DBG(a) & 1)) buf_store1(v, rY, voY, (unsigned)rr * ldy4 + (nt_) * 128u);                \
         if (!(CHECK_) || wm * 64 + rr + 4 * h < nvalid) { s_ += v; q_ = fmaf(v, v, q_); }                  \
     }
-    if (nvalid >= BM) {
-        BUF_EPI(acc00, 0, 0, bias0, s0, q0, false) BUF_EPI(acc10, 1, 0, bias0, s0, q0, false)
-        BUF_EPI(acc01, 0, 1, bias1, s1, q1, false) BUF_EPI(acc11, 1, 1, bias1, s1, q1, false)
-    } else {
-        BUF_EPI(acc00, 0, 0, bias0, s0, q0, true) BUF_EPI(acc10, 1, 0, bias0, s0, q0, true)
-        BUF_EPI(acc01, 0, 1, bias1, s1, q1, true) BUF_EPI(acc11, 1, 1, bias1, s1, q1, true)
-    }
-    if (a.partial && !(PIFU_DBG(a) & 2)) {
-        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
-        s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
-        if (lane < 32) {
-            red[(0 * 2 + wm) * BN + wn * 64 + j] = s0;
-            red[(1 * 2 + wm) * BN + wn * 64 + j] = q0;
-            red[(0 * 2 + wm) * BN + wn * 64 + 32 + j] = s1;
-            red[(1 * 2 + wm) * BN + wn * 64 + 32 + j] = q1;
-        }
-        __syncthreads();
-        if (tid < BN)
-            a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
-                make_float2(red[tid] + red[BN + tid], red[2 * BN + tid] + red[3 * BN + tid]);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_mlp_gemm_tri: k_mlp_gemm_buf with a SINGLE LDS buffer (36 KB) and a register budget of 168, so that THREE blocks fit a
@@ -714,198 +328,12 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_mlp_gemm_wide: the same GEMM on a 128 (points) x 256 (channels) x 16 (K) block tile, for layers whose padded Cout is a
-// multiple of 256.  4 waves, each a 64 x 128 output tile = 2 x 4 MFMA tiles (128 accumulator VGPRs); still 64 MFMAs per
-// wave between two barriers, but an A element (loaded, normalised, activated, written to LDS) now feeds 256 output
-// columns instead of 128, a K step moves 24 KB through LDS staging instead of 32 KB, and 12 instead of 16 fragment
-// reads feed the 64 MFMAs: the non-MFMA work that the fp32 MFMA cannot hide shrinks by about a third.  LDS 61 KB
-// (K step 16, row stride 20 floats) keeps two blocks per CU.  Same k order per accumulator and the same per-128-row
-// statistics partials as k_mlp_gemm_buf: bit-identical results.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_mlp_gemm_wide(const GemmArgs a)
-{
-    constexpr int TBK = 16, LD = TBK + 4, WN = 256, ATILE = BM * LD, BTILE = WN * LD, STG = ATILE + BTILE, NS = TBK / 8;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STG];   // [buf][A | B]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = a.ntn / 2;                    // 256-column tiles
-    const int q_tile = blockIdx.x;
-    const int xcd = q_tile & 7, slot = q_tile >> 3;
-    const int tile_n = slot % ntn;
-    const int tile_m = (slot / ntn) * 8 + xcd;
-    if (tile_m >= a.ntm) return;
-    const int chunk_id = tile_m / a.g.tpc;
-    const size_t row0 = (size_t)tile_m * BM;
-    const int col0 = tile_n * WN;
-
-    const int kq = tid & 3, sr = tid >> 2;        // staging: float4 column kq of rows sr + 64 p
-    const unsigned kb = kq * 16;
-    const int nsteps = a.ldw / TBK;
-    const unsigned ldw4 = (unsigned)a.ldw * 4u;
-    const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
-    const unsigned voW = (unsigned)sr * ldw4 + kb;
-
-    float4 ra0, ra1, rw0, rw1, rw2, rw3, rsc, rsh;
-    float rslope = 1.f;
-    int c_seg = 0, c_left = a.seg[0].width / TBK;
-    unsigned c_ks4 = 0, c_kw4 = 0;
-    unsigned c_ld4 = (unsigned)a.seg[0].ld * 4u;
-    __amdgpu_buffer_rsrc_t c_rA = buf_rsrc(a.seg[0].ptr + row0 * (size_t)a.seg[0].ld);
-    __amdgpu_buffer_rsrc_t c_rsc = buf_rsrc(a.seg[0].scale + (size_t)chunk_id * a.seg[0].sld);
-    __amdgpu_buffer_rsrc_t c_rsh = buf_rsrc(a.seg[0].shift + (size_t)chunk_id * a.seg[0].sld);
-    float c_slope = a.seg[0].mode == 0 ? 1.f : 0.01f;
-    unsigned voA = (unsigned)sr * c_ld4 + kb;
-#define WIDE_GLOAD()                                                                                       \
-    {                                                                                                      \
-        rslope = c_slope;                                                                                  \
-        ra0 = buf_load4(c_rA, voA, c_ks4);                                                                 \
-        ra1 = buf_load4(c_rA, voA, c_ks4 + 64u * c_ld4);                                                   \
-        rsc = buf_load4(c_rsc, kb, c_ks4);                                                                 \
-        rsh = buf_load4(c_rsh, kb, c_ks4);                                                                 \
-        rw0 = buf_load4(rW, voW, c_kw4);                                                                   \
-        rw1 = buf_load4(rW, voW, c_kw4 + 64u * ldw4);                                                      \
-        rw2 = buf_load4(rW, voW, c_kw4 + 128u * ldw4);                                                     \
-        rw3 = buf_load4(rW, voW, c_kw4 + 192u * ldw4);                                                     \
-        c_ks4 += TBK * 4u;                                                                                 \
-        c_kw4 += TBK * 4u;                                                                                 \
-        if (--c_left == 0 && ++c_seg < a.nseg) {                                                           \
-            const float *np_ = c_seg == 1 ? a.seg[1].ptr : a.seg[2].ptr;                                   \
-            const float *nsc_ = c_seg == 1 ? a.seg[1].scale : a.seg[2].scale;                              \
-            const float *nsh_ = c_seg == 1 ? a.seg[1].shift : a.seg[2].shift;                              \
-            const int nld_ = c_seg == 1 ? a.seg[1].ld : a.seg[2].ld;                                       \
-            const int nsld_ = c_seg == 1 ? a.seg[1].sld : a.seg[2].sld;                                    \
-            const int nmd_ = c_seg == 1 ? a.seg[1].mode : a.seg[2].mode;                                   \
-            c_left = (c_seg == 1 ? a.seg[1].width : a.seg[2].width) / TBK;                                 \
-            c_ks4 = 0;                                                                                     \
-            c_ld4 = (unsigned)nld_ * 4u;                                                                   \
-            c_rA = buf_rsrc(np_ + row0 * (size_t)nld_);                                                    \
-            c_rsc = buf_rsrc(nsc_ + (size_t)chunk_id * nsld_);                                             \
-            c_rsh = buf_rsrc(nsh_ + (size_t)chunk_id * nsld_);                                             \
-            c_slope = nmd_ == 0 ? 1.f : 0.01f;                                                             \
-            voA = (unsigned)sr * c_ld4 + kb;                                                               \
-        }                                                                                                  \
-    }
-#define WIDE_LSTORE(buf_)                                                                                  \
-    {                                                                                                      \
-        float *la = lds + (buf_) * STG + sr * LD + kq * 4;                                                 \
-        BUF_XF(ra0) BUF_XF(ra1)                                                                            \
-        *reinterpret_cast<float4 *>(la) = ra0;                                                             \
-        *reinterpret_cast<float4 *>(la + 64 * LD) = ra1;                                                   \
-        *reinterpret_cast<float4 *>(la + ATILE) = rw0;                                                     \
-        *reinterpret_cast<float4 *>(la + ATILE + 64 * LD) = rw1;                                           \
-        *reinterpret_cast<float4 *>(la + ATILE + 128 * LD) = rw2;                                          \
-        *reinterpret_cast<float4 *>(la + ATILE + 192 * LD) = rw3;                                          \
-    }
-
-    const int h = lane >> 5, j = lane & 31;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    WIDE_GLOAD()
-    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z
-        const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
-        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);
-        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
-        float wz[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wz[nt] = a.colwz ? a.colwz[col0 + wn * 128 + nt * 32 + j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
-            const unsigned ciA = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so, 0);
-            const unsigned ciB = __builtin_amdgcn_raw_buffer_load_b32(rI, vrow, so + 128u, 0);
-            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
-            const unsigned qA = ciA * ldq4 + (unsigned)(wn * 128 + j) * 4u, qB = ciB * ldq4 + (unsigned)(wn * 128 + j) * 4u;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                acc[0][nt][r] = fmaf(wz[nt], zA, buf_load1(rQ, qA, nt * 128));
-                acc[1][nt][r] = fmaf(wz[nt], zB, buf_load1(rQ, qB, nt * 128));
-            }
-        }
-    }
-    WIDE_LSTORE(0)
-    __syncthreads();
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) WIDE_GLOAD()
-        const float *A = lds + buf * STG + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        const float *B = lds + buf * STG + ATILE + (wn * 128 + (lane & 31)) * LD + (lane >> 5) * 4;
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
-            float4 bq[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bq[nt] = *reinterpret_cast<const float4 *>(B + nt * 32 * LD + s * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float bv = t == 0 ? bq[nt].x : (t == 1 ? bq[nt].y : (t == 2 ? bq[nt].z : bq[nt].w));
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv, acc[1][nt], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) WIDE_LSTORE(buf ^ 1)
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias, raw store, per-column statistics over the tile's valid rows
-    const int local0 = (tile_m % a.g.tpc) * BM;
-    int nvalid = chunk_len(a.g, chunk_id) - local0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
-    float *red = lds;   // [2 (sum|sq)][2 (wm)][WN]; safe: every wave passed the loop's final barrier
-    const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
-    const unsigned ldy4 = (unsigned)a.ldy * 4u;
-    const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 128 + j) * 4u;
-    float sm[4], sq[4];
-    const bool full = nvalid >= BM;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const float bias = a.bias[col0 + wn * 128 + nt * 32 + j];
-        float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = mt * 32 + (r & 3) + 8 * (r >> 2);
-                const float v = acc[mt][nt][r] + bias;
-                buf_store1(v, rY, voY, (unsigned)rr * ldy4 + nt * 128u);
-                if (full || wm * 64 + rr + 4 * h < nvalid) { s_ += v; q_ = fmaf(v, v, q_); }
-            }
-        sm[nt] = s_; sq[nt] = q_;
-    }
-    if (a.partial) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            sm[nt] += __shfl_xor(sm[nt], 32); sq[nt] += __shfl_xor(sq[nt], 32);
-            if (lane < 32) {
-                red[(0 * 2 + wm) * WN + wn * 128 + nt * 32 + j] = sm[nt];
-                red[(1 * 2 + wm) * WN + wn * 128 + nt * 32 + j] = sq[nt];
-            }
-        }
-        __syncthreads();
-        a.partial[(size_t)tile_m * a.ldy + col0 + tid] =
-            make_float2(red[tid] + red[WN + tid], red[2 * WN + tid] + red[3 * WN + tid]);
-    }
-#undef WIDE_GLOAD
-#undef WIDE_LSTORE
-}
-
+#ifdef PIFU_LAB
+// lab builds only (tools/lab): the predecessors of k_mlp_gemm_tri (bit-identity A/B) and the rejected schedules
+#include "gemm_predecessors.inc"
 #ifdef PIFU_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
+#endif
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1124,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
         }                                                                                                  \
     }
     // step t: issue the loads of step t+2 (into the set step t used), compute step t, stage step t+1 (other set)
+#ifdef PIFU_LAB
 #define BF3_STAMP(slot_)                                                                                   \
     if (a.stamps) {                                                                                        \
         unsigned long long ts_;                                                                            \
@@ -1132,6 +561,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         if (tid == 0 && blockIdx.x < 64 && t < 40) a.stamps[((size_t)blockIdx.x * 40 + t) * 4 + (slot_)] = ts_; \
     }
+#else
+#define BF3_STAMP(slot_)
+#endif
 #define BF3_STEP(t_, SC_, SN_)                                                                             \
     {                                                                                                      \
         const int t = (t_);                                                                                \
@@ -1330,6 +762,13 @@ struct SampleArgs {
     ChunkGeom g;
 };
 
+// One row of [g, 1] . calib_inv^T (mesh_util.py:64) in float64, as a fused chain in k order - what a BLAS dgemm
+// micro-kernel evaluates for this 4-term dot product - and independent of the compiler's contraction choices.
+__device__ __forceinline__ double lattice_dot(double gx, double gy, double gz, const double *m)
+{
+    return __fma_rn(1.0, m[3], __fma_rn(gz, m[2], __fma_rn(gy, m[1], __dmul_rn(gx, m[0]))));
+}
+
 __device__ __forceinline__ void bilinear_setup(float u, float v, int W, int H, int (&off)[4], float (&wt)[4])
 {
     // grid_sample(align_corners=True, padding zeros) as used by index() (BasePIFuNet.py:22)
@@ -1384,9 +823,9 @@ __global__ void k_sample(const SampleArgs a)
         const double gy = __dadd_rn(__dmul_rn((double)gj, 2.0 / a.src.res[1]), -1.0);
         const double gz = __dadd_rn(__dmul_rn((double)gk, 2.0 / a.src.res[2]), -1.0);
         const double *m = a.src.cinv;   // [g,1] . calib_inv^T (mesh_util.py:64), then .float() (mesh_util.py:70)
-        px = (float)(gx * m[0] + gy * m[1] + gz * m[2] + m[3]);
-        py = (float)(gx * m[4] + gy * m[5] + gz * m[6] + m[7]);
-        pz = (float)(gx * m[8] + gy * m[9] + gz * m[10] + m[11]);
+        px = (float)lattice_dot(gx, gy, gz, m);
+        py = (float)lattice_dot(gx, gy, gz, m + 4);
+        pz = (float)lattice_dot(gx, gy, gz, m + 8);
     }
     // orthogonal(): xyz = R p + t (BasePIFuNet.py:25-43)
     const float *k = a.calib;
@@ -1452,9 +891,9 @@ __global__ void k_sample_col(const SampleArgs a, float *zf, int *colidx, int64_t
     const double gy = __dadd_rn(__dmul_rn((double)gj, 2.0 / a.src.res[1]), -1.0);
     const double gz = __dadd_rn(__dmul_rn((double)gk, 2.0 / a.src.res[2]), -1.0);
     const double *m = a.src.cinv;
-    const float px = (float)(gx * m[0] + gy * m[1] + gz * m[2] + m[3]);
-    const float py = (float)(gx * m[4] + gy * m[5] + gz * m[6] + m[7]);
-    const float pz = (float)(gx * m[8] + gy * m[9] + gz * m[10] + m[11]);
+    const float px = (float)lattice_dot(gx, gy, gz, m);
+    const float py = (float)lattice_dot(gx, gy, gz, m + 4);
+    const float pz = (float)lattice_dot(gx, gy, gz, m + 8);
     const float *k = a.calib;
     const float x = fmaf(k[2], pz, fmaf(k[1], py, fmaf(k[0], px, k[3])));
     const float y = fmaf(k[6], pz, fmaf(k[5], py, fmaf(k[4], px, k[7])));
@@ -1706,74 +1145,31 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
 
 static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st);
 
-// work-queue counters of one k_mlp_gemm_dyn launch: a ring of zeroed 8-int slots, re-zeroed (stream-ordered) on wrap
-static int *next_tile_counters(pifu_ctx *ctx, hipStream_t st)
-{
-    constexpr int SLOTS = 4096;
-    if (!ctx->tile_ctr) {
-        if (hipMalloc(&ctx->tile_ctr, SLOTS * 8 * sizeof(int)) != hipSuccess) { ctx->tile_ctr = nullptr; return nullptr; }
-        ctx->tile_ctr_next = SLOTS;      // forces the first memset
-    }
-    if (ctx->tile_ctr_next >= SLOTS) {
-        if (hipMemsetAsync(ctx->tile_ctr, 0, SLOTS * 8 * sizeof(int), st) != hipSuccess) return nullptr;
-        ctx->tile_ctr_next = 0;
-    }
-    return (int *)ctx->tile_ctr + 8 * ctx->tile_ctr_next++;
-}
+#ifdef PIFU_LAB
+#include "gemm_dispatch.inc"
+#endif
 
-// exact-fp32 GEMM dispatch (EXPERIMENTS builds: PIFU_GEMM_VARIANT=13 selects the rejected 256-row tile kernel when a
-// 256-row tile cannot straddle a chunk; PIFU_GEMM_DBG ablates parts of the kernel for timing studies)
+// exact-fp32 GEMM launch: k_mlp_gemm_tri, three blocks per CU, no s_setprio (with three waves per SIMD raising the MFMA
+// phase's priority costs 1.2 %; with two it gains 1-2 %)
 static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
 {
-#ifdef PIFU_GEMM_EXPERIMENTS
-    if (ctx->gemm_variant == 13 && a.ntm % 2 == 0 && a.g.tpc % 2 == 0) {
-        const int ntm2 = a.ntm / 2;
-        if (a.ntn % 2 == 0)
-            hipLaunchKernelGGL(k_mlp_gemm_big<4>, dim3((unsigned)round_up(ntm2, 8) * (a.ntn / 2)), dim3(512), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_mlp_gemm_big<2>, dim3((unsigned)round_up(ntm2, 8) * a.ntn), dim3(512), 0, st, a);
-        return;
-    }
-    GemmArgs b = a;
-    if (const char *v = getenv("PIFU_GEMM_DBG")) b.dbg = atoi(v);
-    if ((ctx->gemm_variant == 22 || ctx->gemm_variant == 25) && a.ldw / 32 >= 3) {      // persistent blocks, dynamic per-XCD tile queues (25: no s_setprio)
-        const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
-        b.tile_ctr = next_tile_counters(ctx, st);
-        b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
-        if (b.tile_ctr) {
-            if (ctx->gemm_variant == 22) hipLaunchKernelGGL(k_mlp_gemm_dyn<true>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
-            else hipLaunchKernelGGL(k_mlp_gemm_dyn<false>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
-            return;
-        }
-    }
-    if (ctx->gemm_variant == 20 || ctx->gemm_variant == 26) {      // persistent blocks with cross-tile prefetch (26: no s_setprio) (rejected: same speed, see gemm_experiments.inc)
-        const unsigned nb = (unsigned)round_up(a.ntm, 8) * a.ntn, cap = 2u * (unsigned)ctx->num_cus / 8u * 8u;
-        b.stamps = (ctx->debug_buf && a.ldw == 256 && a.ntn == 4) ? (unsigned long long *)ctx->debug_buf : nullptr;   // fine L0
-        if (ctx->gemm_variant == 20) hipLaunchKernelGGL(k_mlp_gemm_pers<true>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
-        else hipLaunchKernelGGL(k_mlp_gemm_pers<false>, dim3(nb < cap ? nb : cap), dim3(256), 0, st, b);
-    } else if (ctx->gemm_variant == 6) {
-        b.stamps = (ctx->debug_buf && a.ldw == 1024) ? (unsigned long long *)ctx->debug_buf : nullptr;   // coarse L1 only
-        hipLaunchKernelGGL(k_mlp_gemm_buf2, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
-    } else if (ctx->gemm_variant == 4)
-        hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
-    else if (ctx->gemm_variant == 28)
-        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
-    else
-        hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, b);
+#ifdef PIFU_LAB
+    if (lab_launch_fp32_gemm(ctx, a, st)) return;
+#endif
+    (void)ctx;
+    hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+}
+
+static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st);
+
+// partial rows per 128-row tile that k_norm_finalize sums (lab builds: 2 for the half-tile partials of k_mlp_gemm_ws)
+static inline int stat_halves(const pifu_ctx *ctx)
+{
+#ifdef PIFU_LAB
+    return lab_stat_halves(ctx);
 #else
-    if (ctx->gemm_variant == 4)     // A/B aid: the pointer-addressed kernel
-        hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else if (ctx->gemm_variant == 28)   // the two-blocks-per-CU, double-buffered predecessor of the default
-        hipLaunchKernelGGL(k_mlp_gemm_buf<true>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else if (ctx->gemm_variant == 21 && a.ntn % 2 == 0)
-        hipLaunchKernelGGL(k_mlp_gemm_wide, dim3((unsigned)round_up(a.ntm, 8) * (a.ntn / 2)), dim3(256), 0, st, a);
-    else if (ctx->gemm_variant == 24)
-        hipLaunchKernelGGL(k_mlp_gemm_buf<false>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else if (ctx->gemm_variant == 30)   // the default with its MFMA phase at s_setprio 3 (what the two-block kernels want)
-        hipLaunchKernelGGL(k_mlp_gemm_tri<3>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else                                // default: three blocks per CU, no s_setprio (with three waves per SIMD raising the MFMA
-                                        // phase's priority costs 1.2 %; with two it gains 1-2 %)
-        hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    (void)ctx;
+    return 1;
 #endif
 }
 
@@ -1814,87 +1210,16 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             const bool stats = (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN);
             a.partial = stats ? b.partial[i] : nullptr;
             a.ntm = ntm; a.ntn = l.cout_pad / BN; a.g = g;
-            const int nblocks = (int)round_up(ntm, 8) * a.ntn;
-            a.nsteps = l.kpad / BK;
-            bool table_ok = a.nsteps <= 40 && (size_t)rows * 4 * (size_t)l.kpad < ((size_t)1 << 32);
-            if (table_ok) {
-                int st_i = 0;
-                for (int sgi = 0; sgi < ns; ++sgi)
-                    for (int k0 = 0; k0 < segs[sgi].width; k0 += BK, ++st_i) {
-                        GemmArgs::StepDesc &d = a.steps[st_i];
-                        d.ptr = segs[sgi].ptr + k0;
-                        d.scale = segs[sgi].scale + k0;
-                        d.shift = segs[sgi].shift + k0;
-                        d.ld4 = segs[sgi].ld * 4;
-                        d.sld = segs[sgi].sld;
-                        d.mode = segs[sgi].mode;
-                        if ((size_t)rows * d.ld4 >= ((size_t)1 << 32) || d.ld4 >= (1 << 24) || rows >= (1 << 24)) table_ok = false;
-                    }
-            }
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (ctx->prof_on) {
-                if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-                    hipEvent_t a0, a1;
-                    PIFU_HIP(hipEventCreate(&a0));
-                    PIFU_HIP(hipEventCreate(&a1));
-                    ctx->prof_ev.push_back(a0);
-                    ctx->prof_ev.push_back(a1);
-                }
-                e0 = ctx->prof_ev[ctx->prof_used];
-                e1 = ctx->prof_ev[ctx->prof_used + 1];
-                ctx->prof_used += 2;
-                PIFU_HIP(hipEventRecord(e0, st));
-            }
-            if (ctx->precision != 0) {
-                if (!table_ok) a.nsteps = 0;
-                int rc2 = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
-                if (rc2) return rc2;
-                a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
-                if (ctx->precision == 2) hipLaunchKernelGGL(k_mlp_gemm_split<1>, dim3(nblocks), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL(k_mlp_gemm_split<0>, dim3(nblocks), dim3(256), 0, st, a);
-            } else
-            {
-#ifdef PIFU_GEMM_EXPERIMENTS
-            switch (ctx->gemm_variant) {
-            case 0: hipLaunchKernelGGL((k_mlp_gemm<32, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 1: hipLaunchKernelGGL((k_mlp_gemm<32, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((k_mlp_gemm<16, 0>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 3: hipLaunchKernelGGL((k_mlp_gemm<16, 1>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 4: hipLaunchKernelGGL((k_mlp_gemm<32, 3>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 6: hipLaunchKernelGGL((k_mlp_gemm_ring<16>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 7: hipLaunchKernelGGL((k_mlp_gemm_ring<32>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 8: a.stamps = (ctx->debug_buf && L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
-                    hipLaunchKernelGGL(k_mlp_gemm_ws, dim3(ctx->num_cus), dim3(512), 0, st, a); break;
-            case 9: a.stamps = (L == 0 && i == 1) ? (unsigned long long *)ctx->debug_buf : nullptr;
-                    hipLaunchKernelGGL((k_mlp_gemm<32, 2>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 10: if (table_ok) { hipLaunchKernelGGL(k_mlp_gemm_v2, dim3(nblocks), dim3(256), 0, st, a); break; }
-                     hipLaunchKernelGGL((k_mlp_gemm<32, 4>), dim3(nblocks), dim3(256), 0, st, a); break;
-            case 11: hipLaunchKernelGGL((k_mlp_gemm<32, 5>), dim3(std::min(nblocks, 2 * ctx->num_cus)), dim3(256), 0, st, a); break;
-            default: launch_fp32_gemm(ctx, a, st); break;
-            }
-#else
-            (void)table_ok; (void)nblocks;
-            launch_fp32_gemm(ctx, a, st);
-#endif
-            }
-            if (ctx->prof_on) {
-                PIFU_HIP(hipEventRecord(e1, st));
-                const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
-                ctx->prof_flops += 2.0 * valid * l.cout * (double)(l.cin_prev + l.cin_feat);
-                ctx->prof_launches += 1;
-            }
+            const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
+            int rc2 = run_gemm(ctx, a, 2.0 * valid * l.cout * (double)(l.cin_prev + l.cin_feat), st);
+            if (rc2) return rc2;
             if (stats) {
                 const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                 const int cpg = l.cout / groups;
                 const int nw = g.nchunks * groups;
                 hipLaunchKernelGGL(k_norm_finalize, dim3(nw), dim3(256), 0, st, (const float2 *)b.partial[i],
                                    l.cout_pad, cpg, groups, (const float *)l.gamma, (const float *)l.beta, b.scale[i],
-                                   b.shift[i], g, 1e-5f,
-#ifdef PIFU_GEMM_EXPERIMENTS
-                                   ctx->gemm_variant == 8 ? 2 : 1
-#else
-                                   1
-#endif
+                                   b.shift[i], g, 1e-5f, stat_halves(ctx)
                                    );
             }
         } else {

@@ -60,10 +60,11 @@ def eval_lattice_sharded(net, calib_tensor, res, chunk, flags=0, group=None):
     """Dense lattice res[0] x res[1] x res[2] evaluated across all ranks; returns fp32 [prod(res)]."""
     from . import _lib
     from .nets import _ptr, _stream_ptr
-    ctx = net._ctx
+    from .mesh_util import _ctx_of
+    ctx = _ctx_of(net)
     dev = ctx.device
-    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
-    calib_inv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    from .mesh_util import calib_pair
+    calib, calib_inv = calib_pair(calib_tensor)
     res_a = (C.c_int32 * 3)(*[int(r) for r in res])
     total = int(res[0]) * int(res[1]) * int(res[2])
 
@@ -81,11 +82,12 @@ def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, th
     all ranks end with the identical float64 SDF.  Returns (sdf [R,R,R] float64 device tensor, evaluated)."""
     from . import _lib
     from .nets import _ptr, _stream_ptr
-    ctx = net._ctx
+    from .mesh_util import _ctx_of
+    ctx = _ctx_of(net)
     dev = ctx.device
     st = _stream_ptr(dev)
-    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
-    calib_inv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    from .mesh_util import calib_pair
+    calib, calib_inv = calib_pair(calib_tensor)
     res_a = (C.c_int32 * 3)(R, R, R)
     sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
     notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8)

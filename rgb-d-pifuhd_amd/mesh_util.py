@@ -32,8 +32,16 @@ def create_grid(resX, resY, resZ, b_min=np.array([-1, -1, -1]), b_max=np.array([
     return coords.reshape(3, resX, resY, resZ), mat
 
 
+def calib_pair(calib_tensor):
+    """(calib float32 [4,4], calib_inv float64 [4,4]) as the reference forms them (`mesh_util.py:61-62`): the inverse is
+    taken of the FLOAT32 matrix (numpy inverts in float32) and only then promoted, when it meets the float64 grid."""
+    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
+    return calib, np.ascontiguousarray(inv(calib).astype(np.float64))
+
+
 def _ctx_of(net):
     if isinstance(net, (PIFuMRNet, PIFuNetwNML)):
+        net._sync_weights()          # pending load_state_dict / train-eval changes reach the device before any direct call
         return net._ctx
     raise TypeError('net must be a pifuhd_amd PIFuMRNet / PIFuNetwNML')
 
@@ -45,8 +53,7 @@ def eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree, ini
     ctx = _ctx_of(net)
     dev = ctx.device
     R = int(resolution)
-    calib = np.ascontiguousarray(calib_tensor[0].detach().cpu().numpy().astype(np.float32))
-    calib_inv = np.ascontiguousarray(inv(calib.astype(np.float64)))        # mesh_util.py:61-62
+    calib, calib_inv = calib_pair(calib_tensor)
     sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
     notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8) if use_octree else None
     flags = 0
@@ -108,7 +115,7 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
         verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
         verts = verts_d.cpu().numpy()
         faces = faces_d.cpu().numpy()
-        calib_inv = inv(calib_tensor[0].detach().cpu().numpy().astype(np.float64))
+        _, calib_inv = calib_pair(calib_tensor)
         mat = np.eye(4)
         mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
         mat[0:3, 3] = -1.0

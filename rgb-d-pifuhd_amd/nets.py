@@ -86,6 +86,26 @@ def _push_mlp(ctx, level, sd, prefix, dims, res_layers, merge_layer, norm_code):
         _lib.call('pifu_mlp_set_layer', ctx.h, level, i, wp, bp, gp, bep, rmp, rvp)
 
 
+def _check_state_dict(owner, spec, given_keys, state_dict, strict, prefix=''):
+    """The checks of `nn.Module.load_state_dict` (what the reference's `netMR.load_state_dict(...)` runs,
+    `reconstruction.py:300`): size mismatches always raise; missing and unexpected keys raise in strict mode, with
+    torch's wording."""
+    errors = []
+    for k, shape in spec.items():
+        if k in state_dict and tuple(state_dict[k].shape) != tuple(shape):
+            errors.append(f'size mismatch for {k[len(prefix):]}: copying a param with shape {tuple(state_dict[k].shape)} from '
+                          f'checkpoint, the shape in current model is {tuple(shape)}.')
+    if strict:
+        missing = [k[len(prefix):] for k in spec if k not in state_dict]
+        unexpected = [k[len(prefix):] for k in given_keys if k not in spec]
+        if unexpected:
+            errors.insert(0, 'Unexpected key(s) in state_dict: {}. '.format(', '.join(f'"{k}"' for k in unexpected)))
+        if missing:
+            errors.insert(0, 'Missing key(s) in state_dict: {}. '.format(', '.join(f'"{k}"' for k in missing)))
+    if errors:
+        raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(owner, '\n\t'.join(errors)))
+
+
 _ENC_NORM = {('batch', False): 0, ('batch', True): 1, ('group', False): 2, ('group', True): 2}
 
 
@@ -181,18 +201,18 @@ class PIFuNetwNML(BasePIFuNet):
         self.netF = 'netF' if getattr(opt, 'use_front_normal', False) else None
         self.netB = 'netB' if getattr(opt, 'use_back_normal', False) else None
         self._last_n = 0
+        self._dirty, self._pushed_code = True, None
 
     # -- parameters --------------------------------------------------------------------------------
-    def load_state_dict(self, state_dict, strict=True, _prefix=''):
+    def load_state_dict(self, state_dict, strict=True, _prefix='', _check=True):
         from . import synth
         spec = synth.coarse_spec(self.opt, _prefix)
-        missing = [k for k in spec if k not in state_dict]
-        if strict and missing:
-            raise KeyError(f'missing keys in state dict: {missing[:5]} ...')
+        if _check:
+            _check_state_dict('PIFuNetwNML', spec, [k for k in state_dict if k.startswith(_prefix)], state_dict, strict, _prefix)
         self._sd = {k[len(_prefix):]: state_dict[k].detach().to(self.device, torch.float32)
                     if state_dict[k].dtype.is_floating_point else state_dict[k]
                     for k in spec if k in state_dict}
-        self._push_weights()
+        self._dirty = True
 
     def state_dict(self):
         """Flat dict keyed like the reference module's `state_dict()` (no 'netG.' prefix)."""
@@ -217,7 +237,7 @@ class PIFuNetwNML(BasePIFuNet):
                     not_init.add(k[len(part):].split('.')[0])
             print(label, sorted(not_init))
         self._sd = mine
-        self._push_weights()
+        self._dirty = True
 
     def _push_weights(self):
         o = self.opt
@@ -227,19 +247,24 @@ class PIFuNetwNML(BasePIFuNet):
                   int(o.merge_layer), code)
         _lib.call('pifu_set_depth_normalizer', self._ctx.h, float(o.loadSize // 2), float(o.z_size))
         _push_encoder_params(self._ctx, self._sd, '')
+        self._dirty, self._pushed_code = False, code
+
+    def _sync_weights(self):
+        """Upload the weights when they (or the train/eval mode the MLP norm depends on) changed since the last upload:
+        `load_state_dict` and `train()` only mark, so `recon()`'s load -> `eval()` sequence uploads once."""
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter() / query()')
+        if self._dirty or self._pushed_code != _mlp_norm_code(self.opt.mlp_norm, self.training):
+            self._push_weights()
 
     def train(self, mode=True):
-        changed = mode != self.training
         self.training = mode
-        if changed and self._sd is not None and self.opt.mlp_norm == 'batch':
-            self._push_weights()
         return self
 
     # -- filter ------------------------------------------------------------------------------------
     def filter(self, images):
         """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`)."""
-        if self._sd is None:
-            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter()')
+        self._sync_weights()
         images = images.to(self.device, torch.float32).contiguous()
         if images.dim() != 4 or images.shape[0] != 1:
             raise NotImplementedError('images [1,C,H,W] (batch size 1, the reconstruction path)')
@@ -280,6 +305,7 @@ class PIFuNetwNML(BasePIFuNet):
         self._check_unsupported(transforms, labels)
         if not self.im_feat_list:
             raise _lib.PifuError(_lib.ERR_STATE, 'filter() must precede query()')
+        self._sync_weights()
         pts = points.to(self.device, torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[0] != 1 or pts.shape[1] != 3:
             raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
@@ -324,30 +350,26 @@ class PIFuMRNet(BasePIFuNet):
         self.preds_low = None
         self.normx = None
         self.training = True          # a freshly constructed module is in train mode (SURVEY C-2)
+        self._dirty, self._pushed_code = True, None
 
     def train(self, mode=True):
         """`PIFuMRNet.train` (`PIFuMRNet.py:59-69`): netG is forced to eval unless train_full_pifu."""
-        changed = mode != self.training
         self.training = mode
         if not getattr(self.opt, 'train_full_pifu', False):
             self.netG.eval()
-        if changed and self._sd is not None and self.opt.mlp_norm == 'batch':
-            self._push_weights()
         return self
 
     def load_state_dict(self, state_dict, strict=True):
         from . import synth
-        self.netG.load_state_dict(state_dict, strict, _prefix='netG.')
+        _check_state_dict('PIFuMRNet', synth.state_dict_spec(self.netG.opt, self.opt), list(state_dict), state_dict, strict)
+        self.netG.load_state_dict(state_dict, strict, _prefix='netG.', _check=False)
         own = {}
         synth.filter_keys('image_filter', self.opt.num_stack, self.opt.hg_depth,
                           synth.image_filter_in_channels(self.netG.opt), self.opt.hg_dim, self.opt.norm, 'no_down', own)
         synth.mlp_keys('mlp', self.opt.mlp_dim, self.opt.mlp_res_layers, self.opt.mlp_norm, own)
-        missing = [k for k in own if k not in state_dict]
-        if strict and missing:
-            raise KeyError(f'missing keys in state dict: {missing[:5]} ...')
         self._sd = {k: state_dict[k].detach().to(self.device, torch.float32)
                     if state_dict[k].dtype.is_floating_point else state_dict[k] for k in own if k in state_dict}
-        self._push_weights()
+        self._dirty = True
 
     def state_dict(self):
         """Flat dict with the reference's key scheme: own tensors + the coarse net's under 'netG.'."""
@@ -360,8 +382,19 @@ class PIFuMRNet(BasePIFuNet):
     def _push_weights(self):
         o = self.opt
         code = _mlp_norm_code(o.mlp_norm, self.training)      # train mode => per-chunk batch statistics (C-2)
+        self.netG._sync_weights()                               # the fine MLP is defined against the coarse one
         _push_mlp(self._ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
         _push_encoder_params(self._ctx, self._sd, 'fine.')
+        self._dirty, self._pushed_code = False, code
+
+    def _sync_weights(self):
+        if self._sd is None:
+            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter_local() / query()')
+        coarse_repush = self.netG._dirty or self.netG._pushed_code != _mlp_norm_code(self.netG.opt.mlp_norm, self.netG.training)
+        self.netG._sync_weights()
+        # re-defining the coarse MLP invalidates the fine definition (pifu_mlp_define of the coarse level resets both)
+        if coarse_repush or self._dirty or self._pushed_code != _mlp_norm_code(self.opt.mlp_norm, self.training):
+            self._push_weights()
 
     # -- filter ------------------------------------------------------------------------------------
     def filter_global(self, images):
@@ -372,8 +405,7 @@ class PIFuMRNet(BasePIFuNet):
         """`PIFuMRNet.filter_local` (`PIFuMRNet.py:83-118`): images [1,1,C,H,W]."""
         if rect is not None:
             raise NotImplementedError('`rect` crops are never used on the reconstruction path')
-        if self._sd is None:
-            raise _lib.PifuError(_lib.ERR_STATE, 'load_state_dict() must precede filter_local()')
+        self._sync_weights()
         images = images.to(self.device, torch.float32)
         if images.dim() != 5 or images.shape[0] != 1 or images.shape[1] != 1:
             raise NotImplementedError('images [1,1,C,H,W] (single view, the reconstruction path)')
@@ -422,6 +454,7 @@ class PIFuMRNet(BasePIFuNet):
                 raise NotImplementedError('different local/global calibrations (crop training) are out of scope')
         if not self.im_feat_list or not self.netG.im_feat_list:
             raise _lib.PifuError(_lib.ERR_STATE, 'filter_global()/filter_local() must precede query()')
+        self._sync_weights()
         pts = points.to(self.device, torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[0] != 1 or pts.shape[1] != 3:
             raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
@@ -493,6 +526,7 @@ class PIFuMRNet(BasePIFuNet):
         if n == 0:
             # the reference crashes inside Conv1d on an empty slice (SURVEY C-6)
             raise RuntimeError('calc_normal on an empty vertex slice')
+        self._sync_weights()
         calib, calib_p = _host_f32(calib_global[0])
         out = torch.empty(3, n, device=self.device, dtype=torch.float32)
         _lib.call('pifu_calc_normal', self._ctx.h, _ptr(pts), n, calib_p, float(delta), _ptr(out),
@@ -509,6 +543,7 @@ class PIFuMRNet(BasePIFuNet):
         n = pts.shape[1]
         if n == 0:
             raise RuntimeError('calc_normal on an empty vertex slice')
+        self._sync_weights()
         calib, calib_p = _host_f32(calib_global[0])
         out = torch.empty(3, n, device=self.device, dtype=torch.float32)
         _lib.call('pifu_calc_normal_chunked', self._ctx.h, _ptr(pts), n, int(interval), calib_p, float(delta), _ptr(out),

@@ -29,6 +29,19 @@ def test_header_symbols_exported_and_bound(lib):
     assert handle.pifu_abi_version() == 1
 
 
+def test_library_exports_exactly_the_header(lib):
+    """No lab switches or diagnostics in the shipped library: its `pifu_*` exports are the header's declarations."""
+    header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
+    declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header)) - {'pifu_ctx', 'pifu_stream'}
+    lib.load()
+    out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('pifu_')}
+    assert exported == declared, exported ^ declared
+    blob = open(lib.LIB_PATH, 'rb').read()
+    for switch in (b'PIFU_GEMM_VARIANT', b'PIFU_COLUMN_MODE', b'PIFU_DEPTH_WALK', b'PIFU_PRECISION', b'PIFU_DEBUG_STAMPS'):
+        assert switch not in blob, switch
+
+
 def test_no_cpu_fallback(lib):
     """The product path refuses to run without a GPU instead of silently computing elsewhere."""
     import torch
@@ -61,7 +74,9 @@ def test_obj_writer_host_only(lib, tmp_path):
     # random values + exact rounding ties (k/32, odd/20000), signed zeros, tiny negatives, large magnitudes
     v = np.concatenate([rs.randn(5000, 3) * 3, rs.randint(-64, 64, size=(600, 3)) / 32.0,
                         (rs.randint(0, 20000, size=(600, 3)) * 2 + 1) / 20000.0,
-                        np.array([[0.0, -0.0, 1e-9], [-1e-9, 0.00005, -0.00005], [123456.78905, -99999.99995, 1e10]])])
+                        np.array([[0.0, -0.0, 1e-9], [-1e-9, 0.00005, -0.00005], [123456.78905, -99999.99995, 1e10]]),
+                        # outside the fast formatter: huge finite values (315 characters), infinities, NaNs of either sign
+                        np.array([[1.7e308, -1.7e308, 1e11], [np.inf, -np.inf, np.nan], [-np.nan, 3e200, -2.5e15]])])
     c = rs.rand(len(v), 3)
     f = rs.randint(0, len(v), size=(8000, 3)).astype(np.int32)
     p = tmp_path / 'a.obj'

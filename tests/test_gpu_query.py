@@ -285,10 +285,14 @@ def test_supervised_forward_matches_reference():
 
 
 def test_default_gemm_is_bit_identical_to_its_predecessors():
-    """k_mlp_gemm_tri (default: one LDS buffer, three blocks per CU), k_mlp_gemm_buf (variant 28) and the pointer-addressed
-    k_mlp_gemm (variant 4) use the same tiles, k order and statistics partials: the occupancy must match bit for bit, on the
+    """k_mlp_gemm_tri (the shipped kernel: one LDS buffer, three blocks per CU) against its predecessors k_mlp_gemm_buf
+    (variant 28) and the pointer-addressed k_mlp_gemm (variant 4), which only exist in the lab build of the same sources
+    (tools/lab, -DPIFU_LAB): same tiles, k order and statistics partials, so the occupancy must match bit for bit, on the
     per-point path and on the column-sharing lattice path."""
     import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'lab'))
+    import lab
     from pifuhd_amd import _lib, nets
     from pifuhd_amd.nets import _ptr, _stream_ptr
     sd, oc, of = golden_nets()
@@ -298,26 +302,35 @@ def test_default_gemm_is_bit_identical_to_its_predecessors():
     res = (C.c_int32 * 3)(20, 24, 56)
     total = 20 * 24 * 56
     pts = seeded_points(9, 3210)
+
+    def run():
+        netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+        fc, ff = seeded_features(7)
+        netG.set_features(fc)
+        netMR.set_features(ff)
+        netMR.query(pts, calib_t)
+        q = netMR.get_preds()[0, 0].cpu().numpy().copy()
+        lat = torch.empty(total, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  None, 0, total, 700, _lib.Q_FULL_COARSE, _ptr(lat), _stream_ptr(netMR.device))
+        out = (q, lat.cpu().numpy())
+        del netG, netMR
+        return out
+
+    product = run()                                            # the shipped library
     outs = {}
     old = os.environ.get('PIFU_GEMM_VARIANT')
+    prev = lab.use()
     try:
-        for variant in ('5', '28', '4'):
-            os.environ['PIFU_GEMM_VARIANT'] = variant          # read when the context is created
-            netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
-            fc, ff = seeded_features(7)
-            netG.set_features(fc)
-            netMR.set_features(ff)
-            netMR.query(pts, calib_t)
-            q = netMR.get_preds()[0, 0].cpu().numpy().copy()
-            lat = torch.empty(total, device='cuda')
-            _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
-                      None, 0, total, 700, _lib.Q_FULL_COARSE, _ptr(lat), _stream_ptr(netMR.device))
-            outs[variant] = (q, lat.cpu().numpy())
+        for variant in ('28', '4'):
+            os.environ['PIFU_GEMM_VARIANT'] = variant          # read by the LAB library when a context is created
+            outs[variant] = run()
     finally:
+        lab.restore(prev)
         if old is None:
             os.environ.pop('PIFU_GEMM_VARIANT', None)
         else:
             os.environ['PIFU_GEMM_VARIANT'] = old
     for variant in ('28', '4'):
-        assert np.array_equal(outs['5'][0], outs[variant][0]), variant
-        assert np.array_equal(outs['5'][1], outs[variant][1]), variant
+        assert np.array_equal(product[0], outs[variant][0]), variant
+        assert np.array_equal(product[1], outs[variant][1]), variant

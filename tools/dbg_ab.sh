@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 for d in "$@"; do
   OUT=gpurun_out/dbg_$d; rm -rf $OUT; mkdir -p $OUT
-  PIFU_GEMM_DBG=$d rocprofv3 --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 1 --warmup 1 --features synthetic --batch-rows 262144 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass > $OUT/line.json 2> $OUT/err.log
+  PIFU_GEMM_DBG=$d rocprofv3 --kernel-trace --output-format csv -d $OUT -- python tools/lab/bench_lab.py --steps 1 --warmup 1 --features synthetic --batch-rows 262144 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass > $OUT/line.json 2> $OUT/err.log
   python - "$OUT" "$d" <<'P'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]

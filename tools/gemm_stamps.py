@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/lab'); import lab; lab.use()      # lab build: the PIFU_* switches live there
 os.environ.setdefault('PIFU_GEMM_VARIANT', '9'); os.environ['PIFU_DEBUG_STAMPS'] = '1'
 import numpy as np, torch
 import pifuhd_amd

@@ -1,6 +1,6 @@
 """A/B the k_mlp_gemm schedule variants in ONE process, interleaved rounds (cdna guide rule 24)."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/lab'); import lab; lab.use()      # lab build: the PIFU_* switches live there
 import numpy as np, torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, _lib, dist as pdist

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 for v in "$@"; do
   OUT=gpurun_out/lab_$v; rm -rf $OUT; mkdir -p $OUT
-  PIFU_GEMM_VARIANT=$v rocprofv3 --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 1 --warmup 1 --features synthetic --batch-rows 262144 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass > $OUT/line.json 2> $OUT/err.log
+  PIFU_GEMM_VARIANT=$v rocprofv3 --kernel-trace --output-format csv -d $OUT -- python tools/lab/bench_lab.py --steps 1 --warmup 1 --features synthetic --batch-rows 262144 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass > $OUT/line.json 2> $OUT/err.log
   python - "$OUT" "$v" <<'P'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]

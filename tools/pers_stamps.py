@@ -1,7 +1,7 @@
 """Tile life-cycle stamps of k_mlp_gemm_pers (build: make EXPERIMENTS=1 CXXFLAGS+=-DPIFU_PERS_STAMPS; PIFU_GEMM_VARIANT=20) on the fine
 layer 0 (K 256, N 512): [tile start, main loop end, epilogue end] per tile of the first 512 blocks, shader-clock cycles."""
 import ctypes as C, os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/lab'); import lab; lab.use()      # lab build: the PIFU_* switches live there
 os.environ.setdefault('PIFU_GEMM_VARIANT', '20'); os.environ['PIFU_DEBUG_STAMPS'] = '1'
 import numpy as np, torch
 import pifuhd_amd

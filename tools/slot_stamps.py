@@ -1,7 +1,7 @@
 """Block life-cycle stamps of k_mlp_gemm_buf2 (EXPERIMENTS build, PIFU_GEMM_VARIANT=6): prologue, main loop, epilogue,
 and the dispatch gap of a CU slot.  All in shader-clock cycles (s_memtime, per-XCD counters: only same-CU differences)."""
 import ctypes as C, os, sys, collections
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/lab'); import lab; lab.use()      # lab build: the PIFU_* switches live there
 os.environ['PIFU_GEMM_VARIANT'] = '6'; os.environ['PIFU_DEBUG_STAMPS'] = '1'
 import numpy as np, torch
 import pifuhd_amd
