@@ -186,6 +186,15 @@ int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const
 int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
                           float *out, pifu_stream stream);
 
+/* ---- supervised forward: CustomBCELoss.forward (net_util.py:45-66) as used by PIFuMRNet.get_error (PIFuMRNet.py:253-274).
+ * Forward value only (the HIP path has no autograd): mean over [batch][n] of
+ *   -w * (g * t * log(p) + (1 - g) * (1 - t) * log(1 - p)),  p = clamp(pred, 1e-5, 1 - 1e-5),  t = gt (brock: 3 gt - 1)
+ * pred, gt: device fp32 [batch][n]; gamma: device fp32 [batch], or NULL to use fixed_gamma (the loss object's own gamma);
+ * w: NULL (no weighting), device fp32 [batch] (w_per_element = 0) or [batch][n] (w_per_element = 1); out: device fp32 [1].
+ * Deterministic (fixed-order double accumulation). */
+int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, int64_t n, const float *gamma,
+                  float fixed_gamma, const float *w, int w_per_element, int brock, float *out, pifu_stream stream);
+
 /* ---- measurement hook (bench.py / profiles): HIP-event timing of every MLP GEMM launch (k_mlp_gemm_tri) on its own stream --
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms),
  * number of launches and the ALGORITHMIC FLOPs of those launches (2 * valid points * Cout * Cin). */

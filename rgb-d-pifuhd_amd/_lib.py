@@ -59,6 +59,7 @@ SIGNATURES = {
     'pifu_calc_normal_chunked': (_i32, [_p, _p, _i64, _i64, _p, _f, _p, _p]),
     'pifu_index': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
+    'pifu_bce_loss': (_i32, [_p, _p, _p, _i32, _i64, _p, _f, _p, _i32, _i32, _p, _p]),
     'pifu_profile_enable': (_i32, [_p, _i32]),
     'pifu_profile_read': (_i32, [_p, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
     'pifu_clock_probe': (_i32, [_p, _p, _p]),

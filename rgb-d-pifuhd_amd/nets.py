@@ -485,17 +485,21 @@ class PIFuMRNet(BasePIFuNet):
             self.gamma = 1 - self.labels.view(self.labels.size(0), -1).sum(1) / in_bb.view(in_bb.size(0), -1).sum(1)
 
     def get_error(self):
-        """`PIFuMRNet.get_error` (`PIFuMRNet.py:253-274`), including its use of `preds_low` in the fine term."""
+        """`PIFuMRNet.get_error` (`PIFuMRNet.py:253-274`): the occupancy criterion averaged over a stack of predictions.
+        `Err(occ)` (only with train_full_pifu and intermediate losses on) runs over the coarse stacks `preds_low`;
+        `Err(occ:fine)` runs over as many entries as `preds_interm` has but - like the reference - READS `preds_low`;
+        `Err(nml:fine)` appears when normals and their labels are both present."""
+        occ = self.criteria['occ']
+
+        def averaged(count):
+            total = 0.0
+            for i in range(count):
+                total = total + occ(self.preds_low[i], self.labels, self.gamma, self.w)
+            return total / count
         error = {}
         if getattr(self.opt, 'train_full_pifu', False) and not getattr(self.opt, 'no_intermediate_loss', False):
-            error['Err(occ)'] = 0.0
-            for i in range(self.preds_low.size(0)):
-                error['Err(occ)'] += self.criteria['occ'](self.preds_low[i], self.labels, self.gamma, self.w)
-            error['Err(occ)'] /= self.preds_low.size(0)
-        error['Err(occ:fine)'] = 0.0
-        for i in range(self.preds_interm.size(0)):
-            error['Err(occ:fine)'] += self.criteria['occ'](self.preds_low[i], self.labels, self.gamma, self.w)
-        error['Err(occ:fine)'] /= self.preds_interm.size(0)
+            error['Err(occ)'] = averaged(self.preds_low.size(0))
+        error['Err(occ:fine)'] = averaged(self.preds_interm.size(0))
         if self.nmls is not None and self.labels_nml is not None:
             error['Err(nml:fine)'] = self.criteria['nml'](self.nmls, self.labels_nml)
         return error

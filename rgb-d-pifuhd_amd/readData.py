@@ -40,6 +40,42 @@ def _imread_bgr(path):
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
+_IMAGE_EXTENSIONS = ('jpg', 'jpeg', 'png')
+
+
+def _sidecar(path, suffix):
+    """`<image>.<ext>` -> `<image><suffix>`, with the reference's string rule (`readData.py:39,55`): every occurrence of
+    '.<ext>' in the path is replaced, not only the last one."""
+    ext = path.split('.')[-1]
+    return path.replace('.' + ext, suffix)
+
+
+def discover_subjects(root):
+    """Sorted paths of the images under `root` that come with a `<stem>_rect.txt` crop file (`readData.py:36-40`)."""
+    found = []
+    for entry in os.listdir(root):
+        if entry.split('.')[-1].lower() not in _IMAGE_EXTENSIONS:
+            continue
+        path = os.path.join(root, entry)
+        if os.path.exists(_sidecar(path, '_rect.txt')):
+            found.append(path)
+    return sorted(found)
+
+
+def crop_to_world(width, height, rect):
+    """4x4 `calib_world` of a crop (`readData.py:71-79`): uniform zoom `width / rect_w` and the offset of the crop centre
+    from the image centre in NDC units of the full image (x negated, y not).  The arithmetic keeps the reference's
+    order - integer halves, a reciprocal pixel-to-NDC factor - so the float64 entries are bit-identical to it."""
+    x, y, rw, rh = rect
+    zoom = width / rw
+    ndc_per_pixel = 1.0 / float(width // 2)
+    m = np.identity(4) * zoom
+    m[3, 3] = 1.0
+    m[0, 3] = -zoom * (x + rw // 2 - width // 2) * ndc_per_pixel
+    m[1, 3] = zoom * (y + rh // 2 - height // 2) * ndc_per_pixel
+    return m
+
+
 class readDataset:
     """`readDataset` (`readData.py:32-129`)."""
 
@@ -48,10 +84,7 @@ class readDataset:
             raise NotImplementedError('use_crop needs the reference\'s third-party person-segmentation web API')
         self.projection_mode = projection
         self.root = dataroot
-        files = os.listdir(self.root)
-        self.img_files = sorted([os.path.join(self.root, f) for f in files
-                                 if f.split('.')[-1].lower() in ['jpg', 'jpeg', 'png'] and
-                                 os.path.exists(os.path.join(self.root, f.replace('.' + f.split('.')[-1], '_rect.txt')))])
+        self.img_files = discover_subjects(dataroot)
         self.load_size = loadsize
         self.use_crop = use_crop
         self._ctx = _Ctx(device)
@@ -67,44 +100,28 @@ class readDataset:
 
     def get_item(self, index):
         img_path = self.img_files[index]
-        img_name = os.path.splitext(os.path.basename(img_path))[0]
-        ext = img_path.split('.')[-1]
-        rect_path = img_path.replace('.' + ext, '_rect.txt')
-        depth_path = img_path.replace(img_name + '.' + ext, 'depth/depth_' + img_name + '.png')
-        im = _imread_bgr(img_path)
-        h, w = im.shape[:2]
-        rects = np.loadtxt(rect_path, dtype=np.int32)
-        if len(rects.shape) == 1:
-            rects = np.array([rects])
-        rect = rects[0].tolist()
+        name = os.path.splitext(os.path.basename(img_path))[0]
+        depth_path = os.path.join(os.path.dirname(img_path), 'depth', 'depth_' + name + '.png')
+        pixels = _imread_bgr(img_path)
+        height, width = pixels.shape[:2]
+        rect = np.atleast_2d(np.loadtxt(_sidecar(img_path, '_rect.txt'), dtype=np.int32))[0].tolist()
 
-        trans_mat = np.identity(4)                                          # readData.py:71-79
-        scale_im2ndc = 1.0 / float(w // 2)
-        scale = w / rect[2]
-        trans_mat *= scale
-        trans_mat[3, 3] = 1.0
-        trans_mat[0, 3] = -scale * (rect[0] + rect[2] // 2 - w // 2) * scale_im2ndc
-        trans_mat[1, 3] = scale * (rect[1] + rect[3] // 2 - h // 2) * scale_im2ndc
-        intrinsic = np.matmul(trans_mat, np.identity(4))
-        projection_matrix = np.identity(4)
-        projection_matrix[1, 1] = -1
-
-        out = {
-            'name': img_name,
-            'img': self._device_image(im, rect, self.load_size).unsqueeze(0),
-            'img_512': self._device_image(im, rect, 512).unsqueeze(0),
+        flip_y = np.identity(4)
+        flip_y[1, 1] = -1                                                       # the orthographic camera: y up
+        item = {
+            'name': name,
+            'img': self._device_image(pixels, rect, self.load_size).unsqueeze(0),
+            'img_512': self._device_image(pixels, rect, 512).unsqueeze(0),
         }
         if os.path.exists(depth_path):
             depth = _imread_bgr(depth_path)
-            out['depth'] = self._device_image(depth, rect, self.load_size).unsqueeze(0)
-            out['depth_512'] = self._device_image(depth, rect, 512).unsqueeze(0)
-        out.update({
-            'calib': torch.Tensor(projection_matrix).float().unsqueeze(0),
-            'calib_world': torch.Tensor(intrinsic).float().unsqueeze(0),
-            'b_min': np.array([-1, -1, -1]),
-            'b_max': np.array([1, 1, 1]),
-        })
-        return out
+            item['depth'] = self._device_image(depth, rect, self.load_size).unsqueeze(0)
+            item['depth_512'] = self._device_image(depth, rect, 512).unsqueeze(0)
+        item['calib'] = torch.from_numpy(flip_y).float().unsqueeze(0)
+        item['calib_world'] = torch.from_numpy(crop_to_world(width, height, rect)).float().unsqueeze(0)
+        item['b_min'] = np.array([-1, -1, -1])
+        item['b_max'] = np.array([1, 1, 1])
+        return item
 
     def __len__(self):
         return len(self.img_files)

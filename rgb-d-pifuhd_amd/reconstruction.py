@@ -53,6 +53,23 @@ def _normal_spans(n_verts, interval=50000):
     return spans
 
 
+class _Subject:
+    """One subject on the device after both encoders ran: what every `gen_mesh*` variant of the reference starts with
+    (`reconstruction.py:29-45` and its two copies at `:81-97`, `:131-147`)."""
+
+    def __init__(self, net, data):
+        dev = net.device
+        self.calib = data['calib'].to(device=dev)
+        self.image_fine = data['img'].to(device=dev)
+        coarse = data['img_512'].to(device=dev)
+        net.filter_global(coarse)
+        net.filter_local(self.image_fine[:, None])
+        # the strip saved beside the mesh: input | front normal | back normal, as far as the coarse net predicts them
+        tiles = [coarse] + [t for t in (net.netG.nmlF, net.netG.nmlB) if t is not None]
+        self.strip = torch.cat(tiles, 0)
+        self.b_min, self.b_max = data['b_min'], data['b_max']
+
+
 def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None,
              sharded=False):
     """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.
@@ -70,29 +87,15 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
             torch.cuda.synchronize(dev)      # phase times are only meaningful once the queued kernels have finished
         return time.perf_counter()
     t0 = mark()
-    image_tensor_global = data['img_512'].to(device=dev)
-    image_tensor = data['img'].to(device=dev)
-    calib_tensor = data['calib'].to(device=dev)
-
-    net.filter_global(image_tensor_global)
-    net.filter_local(image_tensor[:, None])
+    subj = _Subject(net, data)
+    calib_tensor = subj.calib
     t1 = mark()
-
-    try:
-        if net.netG.netF is not None:
-            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlF], 0)
-        if net.netG.netB is not None:
-            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlB], 0)
-    except Exception:
-        pass
-    b_min = data['b_min']
-    b_max = data['b_max']
-    png_thread = _save_debug_png(save_path[:-4] + '.png', image_tensor_global, background=True) if rank == 0 else None
+    png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
 
     # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
     # like the reference (reconstruction.py:56)
-    verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, b_min, b_max, thresh, use_octree=use_octree,
+    verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh, use_octree=use_octree,
                                         num_samples=5000, sharded=sharded)
     t3 = mark()
     verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
@@ -131,40 +134,30 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     return verts, faces, color
 
 
-def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False):
-    """`gen_mesh_imgColor` (`reconstruction.py:77-125`): same mesh, 100 000-point query chunks, vertex colours sampled
-    from the input image at the projected vertices, vertices mapped back through `calib_world`.  Like the reference,
-    everything after the filters runs inside a try block that prints 'error' and the exception."""
-    dev = net.device
-    image_tensor_global = data['img_512'].to(device=dev)
-    image_tensor = data['img'].to(device=dev)
-    calib_tensor = data['calib'].to(device=dev)
+def _image_coloured_mesh(subj, res, net, cuda, data, save_path, thresh, use_octree):
+    """Mesh with vertex colours looked up in the input image (`reconstruction.py:99-123`): 100 000-point query chunks,
+    colour = bilinear sample of the fine image at the projected vertex, mapped from [-1, 1] to [0, 1]; vertices go back
+    through `calib_world` when the dataset provides one.  Returns (verts, faces, colour)."""
+    _save_debug_png(save_path[:-4] + '.png', subj.strip)
+    verts, faces, _, _ = reconstruction(net, cuda, subj.calib, res, subj.b_min, subj.b_max, thresh, use_octree=use_octree,
+                                        num_samples=100000)
+    on_device = torch.from_numpy(verts.T).unsqueeze(0).to(device=net.device).float()
+    uv = net.projection(on_device, subj.calib[:1])[:, :2, :]
+    colour = index(subj.image_fine[:1], uv, net._ctx)[0].T.detach().cpu().numpy() * 0.5 + 0.5
+    if 'calib_world' in data:
+        to_world = inv(data['calib_world'].numpy()[0])
+        verts = np.matmul(np.concatenate([verts, np.ones_like(verts[:, :1])], 1), to_world.T)[:, :3]
+    return verts, faces, colour
 
-    net.filter_global(image_tensor_global)
-    net.filter_local(image_tensor[:, None])
+
+def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False):
+    """`gen_mesh_imgColor` (`reconstruction.py:77-125`).  Like the reference, a failure after the encoders is reported on
+    stdout ('error' + the exception) instead of raised; the encoders themselves run outside that guard."""
+    subj = _Subject(net, data)
     try:
-        if net.netG.netF is not None:
-            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlF], 0)
-        if net.netG.netB is not None:
-            image_tensor_global = torch.cat([image_tensor_global, net.netG.nmlB], 0)
-    except Exception:
-        pass
-    b_min = data['b_min']
-    b_max = data['b_max']
-    try:
-        _save_debug_png(save_path[:-4] + '.png', image_tensor_global)
-        verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, b_min, b_max, thresh, use_octree=use_octree,
-                                            num_samples=100000)
-        verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
-        xyz_tensor = net.projection(verts_tensor, calib_tensor[:1])
-        uv = xyz_tensor[:, :2, :]
-        color = index(image_tensor[:1], uv, net._ctx).detach().cpu().numpy()[0].T
-        color = color * 0.5 + 0.5
-        if 'calib_world' in data:
-            calib_world = data['calib_world'].numpy()[0]
-            verts = np.matmul(np.concatenate([verts, np.ones_like(verts[:, :1])], 1), inv(calib_world).T)[:, :3]
-        save_obj_mesh_with_color(save_path, verts, faces, color)
-        return verts, faces, color
+        verts, faces, colour = _image_coloured_mesh(subj, res, net, cuda, data, save_path, thresh, use_octree)
+        save_obj_mesh_with_color(save_path, verts, faces, colour)
+        return verts, faces, colour
     except Exception as e:
         print('error')
         print(e)
@@ -174,6 +167,12 @@ def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=Tr
 # ------------------------------------------------------------------------------------------------
 # Checkpoints and the recon() driver (reconstruction.py:232-321)
 # ------------------------------------------------------------------------------------------------
+def gen_mesh_imgColor_plus(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False):
+    """`gen_mesh_imgColor_plus` (`reconstruction.py:127-178`): the image-coloured mesh, reduced to its widest connected
+    component and with the back side recoloured from the silhouette."""
+    raise NotImplementedError('gen_mesh_imgColor_plus (mesh cleaning + back-side recolouring) is not built yet')
+
+
 def load_checkpoint(path, map_location='cpu'):
     """The reference's checkpoint is `{'opt': Namespace, 'opt_netG': Namespace, 'model_state_dict': dict}` written with
     torch.save (`train.py`); `recon` reads it with a plain `torch.load` (`reconstruction.py:253-256`).  Loaded with the
@@ -194,67 +193,64 @@ def save_checkpoint(path, opt, opt_netG, netMR):
                 'model_state_dict': {k: v.detach().cpu() for k, v in netMR.state_dict().items()}}, path)
 
 
+def checkpoint_path(opt):
+    """The file `recon` resumes from (`reconstruction.py:233-240`): an explicit `load_netMR_checkpoint_path` wins, else
+    `<checkpoints_path>/<name>_train_latest` when `resume_epoch` is negative (it is then reset to 0, as the reference
+    does), else `<checkpoints_path>/<name>_train_epoch_<resume_epoch>`."""
+    if opt.load_netMR_checkpoint_path is not None:
+        return opt.load_netMR_checkpoint_path
+    if opt.resume_epoch < 0:
+        opt.resume_epoch = 0
+        return '%s/%s_train_latest' % (opt.checkpoints_path, opt.name)
+    return '%s/%s_train_epoch_%d' % (opt.checkpoints_path, opt.name, opt.resume_epoch)
+
+
+# what the command line keeps when the checkpoint's options replace the caller's (reconstruction.py:261-269)
+_SESSION_OPTIONS = ('dataroot', 'resolution', 'results_path', 'loadSize')
+
+_MESHERS = {0: 'gen_mesh', 1: 'gen_mesh_imgColor', 2: 'gen_mesh_imgColor_plus'}
+
+
 def recon(opt, use_crop=False, use_gpu=True, dataset=None):
-    """`recon` (`reconstruction.py:231-321`): resolve the checkpoint path, overwrite `opt` with the checkpoint's (keeping
-    dataroot / resolution / results_path / loadSize), build both nets, `netG.eval()` only, loop the dataset.
-    `use_gpu=False` raises: this path has no CPU implementation.  `dataset` overrides `readDataset(opt.dataroot, ...)`."""
+    """`recon` (`reconstruction.py:231-321`): load the checkpoint `checkpoint_path(opt)` names (an Exception
+    'Failed loading state dict!' if it does not exist), continue with the CHECKPOINT's options except the session keys
+    dataroot / resolution / results_path / loadSize, build both nets from it, put only netG in eval mode (SURVEY C-2:
+    the fine filter keeps batch statistics) and write `<results_path>/<name>/recon/result_<subject>_<resolution>.obj`
+    for subjects [start_id, end_id) of the dataset; `use_color` selects the colouring (0 normals, 1 image, 2 image +
+    clean-up).  Returns the list of written paths.  `use_gpu=False` raises: this path has no CPU implementation;
+    `dataset` replaces `readDataset(opt.dataroot, ...)`."""
     from .nets import PIFuMRNet, PIFuNetwNML
     from .readData import readDataset
-    if opt.load_netMR_checkpoint_path is not None:
-        state_dict_path = opt.load_netMR_checkpoint_path
-    elif opt.resume_epoch < 0:
-        state_dict_path = '%s/%s_train_latest' % (opt.checkpoints_path, opt.name)
-        opt.resume_epoch = 0
-    else:
-        state_dict_path = '%s/%s_train_epoch_%d' % (opt.checkpoints_path, opt.name, opt.resume_epoch)
+    path = checkpoint_path(opt)
     if not use_gpu:
         raise NotImplementedError('the HIP path needs a GPU (no CPU fallback)')
-    cuda = torch.device('cuda:%d' % opt.gpu_id)
-    start_id, end_id, use_color = opt.start_id, opt.end_id, opt.use_color
+    if path is None or not os.path.exists(path):
+        raise Exception('Failed loading state dict!', path)
+    device = torch.device('cuda:%d' % opt.gpu_id)
+    first, last, colouring = opt.start_id, opt.end_id, opt.use_color
+    ckpt = load_checkpoint(path)
+    run = ckpt['opt']
+    for key in _SESSION_OPTIONS:
+        setattr(run, key, getattr(opt, key))
+    print('checkpoint %s loaded; its options replace the command line except %s' % (path, ', '.join(_SESSION_OPTIONS)))
 
-    if state_dict_path is not None and os.path.exists(state_dict_path):
-        print('Resuming from', state_dict_path)
-        state_dict = load_checkpoint(state_dict_path)
-        print('Load {} success!'.format(state_dict_path))
-        print('Warning: opt is overwritten.')
-        dataroot, resolution, results_path, loadSize = opt.dataroot, opt.resolution, opt.results_path, opt.loadSize
-        opt = state_dict['opt']
-        opt.dataroot, opt.resolution, opt.results_path, opt.loadSize = dataroot, resolution, results_path, loadSize
-        print('Options has been updated!')
-    else:
-        raise Exception('Failed loading state dict!', state_dict_path)
+    subjects = dataset if dataset is not None else readDataset(run.dataroot, run.loadSize, use_crop=use_crop, device=device)
+    print('%d subjects under %s' % (len(subjects), run.dataroot))
+    netG = PIFuNetwNML(ckpt['opt_netG'], subjects.projection_mode, device=device)
+    netMR = PIFuMRNet(run, netG, subjects.projection_mode)
+    netMR.load_state_dict(ckpt['model_state_dict'])
+    netG.eval()                                       # reconstruction.py:288-289,304: netMR itself stays in train mode
 
-    print('Reading test images...')
-    test_dataset = dataset if dataset is not None else readDataset(opt.dataroot, opt.loadSize, use_crop=use_crop, device=cuda)
-    print('Read success!')
-    print('num of test images:', len(test_dataset))
-    projection_mode = test_dataset.projection_mode
-    opt_netG = state_dict['opt_netG']
-    netG = PIFuNetwNML(opt_netG, projection_mode, device=cuda)
-    netMR = PIFuMRNet(opt, netG, projection_mode)
-    netMR.load_state_dict(state_dict['model_state_dict'])
-
-    results_save_path = '{}/{}/recon'.format(opt.results_path, opt.name)
-    os.makedirs(opt.checkpoints_path, exist_ok=True)
-    os.makedirs(opt.results_path, exist_ok=True)
-    os.makedirs(results_save_path, exist_ok=True)
-    start_id = 0 if start_id < 0 else start_id
-    end_id = len(test_dataset) if end_id < 0 else end_id
-    netG.eval()                                       # reconstruction.py:288-289,304: netMR stays in train mode
+    out_dir = '{}/{}/recon'.format(run.results_path, run.name)
+    for d in (run.checkpoints_path, run.results_path, out_dir):
+        os.makedirs(d, exist_ok=True)
     written = []
-    for i in range(start_id, end_id):
-        if i >= len(test_dataset):
-            break
-        test_data = test_dataset[i]
-        result_save_path = results_save_path + '/result_{}_{}.obj'.format(test_data['name'], opt.resolution)
-        print(result_save_path)
-        if use_color == 0:
-            gen_mesh(opt.resolution, netMR, cuda, test_data, result_save_path, components=opt.use_compose)
-        elif use_color == 1:
-            gen_mesh_imgColor(opt.resolution, netMR, cuda, test_data, result_save_path, components=opt.use_compose)
-        elif use_color == 2:
-            raise NotImplementedError('gen_mesh_imgColor_plus (trimesh mesh cleaning + back-side recolouring) is not built')
-        else:
-            raise NameError('unknown downsampling type')      # reconstruction.py:321 (message as in the reference)
-        written.append(result_save_path)
+    for i in range(max(first, 0), len(subjects) if last < 0 else min(last, len(subjects))):
+        subject = subjects[i]
+        target = out_dir + '/result_{}_{}.obj'.format(subject['name'], run.resolution)
+        print(target)
+        if colouring not in _MESHERS:
+            raise NameError('unknown downsampling type')  # reconstruction.py:321 (the reference's wording)
+        globals()[_MESHERS[colouring]](run.resolution, netMR, device, subject, target, components=run.use_compose)
+        written.append(target)
     return written
