@@ -163,15 +163,17 @@ int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream
 
 /* ---- per-vertex normals: PIFuMRNet.calc_normal (PIFuMRNet.py:188-243) as used by gen_mesh -------- */
 /* verts: device fp32 [3][n]; every call is ONE GroupNorm batch of 4n points (p, p+dx, p+dy, p+dz
- * interleaved per point); out: device fp32 [3][n] unit normals. */
+ * interleaved per point); normals: device fp32 [3][n] unit normals; pred4 (device fp32 [4n], may be NULL) receives the
+ * unmasked fine occupancies of those 4n points in that order - the tensor `pred` the reference differences
+ * (PIFuMRNet.py:223-230) - so that parity can be checked on the values, not only on the direction of their differences. */
 int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
-                     float *normals, pifu_stream stream);
+                     float *normals, float *pred4, pifu_stream stream);
 
 /* The colour loop of gen_mesh (reconstruction.py:58-70) in one call: identical to pifu_calc_normal on consecutive
  * slices of `verts_per_call` vertices (the last one shorter) - every slice is its own GroupNorm batch - but several
  * slices share one kernel launch. */
 int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
-                             float delta, float *normals, pifu_stream stream);
+                             float delta, float *normals, float *pred4, pifu_stream stream);
 
 /* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
  * reconstruction.py:112-115): bilinear grid_sample, align_corners=True, zero padding.

@@ -55,8 +55,8 @@ SIGNATURES = {
     'pifu_eval_grid': (_i32, [_p, _i32, _p, _p, _i64, _i32, _d, _i32, _p, _p, C.POINTER(_i64), _p]),
     'pifu_mc_count': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _d, C.POINTER(_i64), C.POINTER(_i64), _p]),
     'pifu_mc_emit': (_i32, [_p, _p, _p, _p]),
-    'pifu_calc_normal': (_i32, [_p, _p, _i64, _p, _f, _p, _p]),
-    'pifu_calc_normal_chunked': (_i32, [_p, _p, _i64, _i64, _p, _f, _p, _p]),
+    'pifu_calc_normal': (_i32, [_p, _p, _i64, _p, _f, _p, _p, _p]),
+    'pifu_calc_normal_chunked': (_i32, [_p, _p, _i64, _i64, _p, _f, _p, _p, _p]),
     'pifu_index': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
     'pifu_bce_loss': (_i32, [_p, _p, _p, _i32, _i64, _p, _f, _p, _i32, _i32, _p, _p]),

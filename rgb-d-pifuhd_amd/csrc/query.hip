@@ -1762,8 +1762,18 @@ int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_i
                            coarse_only ? nullptr : pred, coarse_only ? pred : nullptr, nullptr, 0.f, nullptr, (hipStream_t)stream);
 }
 
+// shared tail of the two calc_normal entry points: differences of the 4n occupancies -> unit normals; optional export of
+// the occupancies themselves (what PIFuMRNet.calc_normal holds in `pred`, PIFuMRNet.py:223-225)
+static int normals_from_pred4(const float *pred4, int64_t n, float *normals, float *pred4_out, hipStream_t st)
+{
+    if (pred4_out) PIFU_HIP(hipMemcpyAsync(pred4_out, pred4, (size_t)4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred4, n, normals);
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
 int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta, float *normals,
-                     pifu_stream stream)
+                     float *pred4_out, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && verts && calib && normals, PIFU_ERR_INVALID, "pifu_calc_normal: null argument");
     PIFU_REQUIRE(n > 0, PIFU_ERR_INVALID, "pifu_calc_normal: empty vertex batch (the reference raises here too)");
@@ -1771,14 +1781,11 @@ int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *
     int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * n, PIFU_Q_NO_FINE_MASK,
                              nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
     if (rc != PIFU_OK) return rc;
-    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)pred4, n, normals);
-    PIFU_HIP(hipGetLastError());
-    return PIFU_OK;
+    return normals_from_pred4(pred4, n, normals, pred4_out, (hipStream_t)stream);
 }
 
 int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
-                             float delta, float *normals, pifu_stream stream)
+                             float delta, float *normals, float *pred4_out, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && verts && calib && normals, PIFU_ERR_INVALID, "pifu_calc_normal_chunked: null argument");
     PIFU_REQUIRE(n > 0 && verts_per_call > 0, PIFU_ERR_INVALID, "pifu_calc_normal_chunked: empty vertex batch");
@@ -1786,10 +1793,7 @@ int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64
     int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * verts_per_call, PIFU_Q_NO_FINE_MASK,
                              nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
     if (rc != PIFU_OK) return rc;
-    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)pred4, n, normals);
-    PIFU_HIP(hipGetLastError());
-    return PIFU_OK;
+    return normals_from_pred4(pred4, n, normals, pred4_out, (hipStream_t)stream);
 }
 
 namespace {

@@ -152,12 +152,37 @@ def eval_grid(coords, eval_func, num_samples=512 * 512 * 512):
     return batch_eval(coords.reshape([3, -1]), eval_func, num_samples=num_samples).reshape(resolution)
 
 
+def lattice_points(resolution, calib_inv, flat_index):
+    """World points [3, n] (float64) of the C-ordered lattice entries `flat_index` of a resolution^3 grid over [-1, 1)^3:
+    `create_grid` followed by the calib^-1 product of `reconstruction` (`mesh_util.py:28-33,59-65`) for those entries only."""
+    R = int(resolution)
+    idx = np.asarray(flat_index, dtype=np.int64)
+    ijk = np.stack([idx // (R * R), (idx // R) % R, idx % R], 1).astype(np.float64)
+    grid = np.concatenate([ijk * (2.0 / R) + (-1.0), np.ones((len(idx), 1))], 1)
+    return np.matmul(grid, np.asarray(calib_inv, dtype=np.float64).T)[:, :3].T
+
+
 def eval_grid_octree(coords, eval_func, init_resolution=64, threshold=0.05, num_samples=512 * 512 * 512,
-                     device='cuda'):
-    """`eval_grid_octree` (`mesh_util.py:124-187`) for an arbitrary host `eval_func`; cubic grids."""
-    R = coords.shape[1]
-    if coords.shape[2] != R or coords.shape[3] != R:
-        raise NotImplementedError('cubic grids only')
+                     device='cuda', resolution=None, calib_inv=None):
+    """`eval_grid_octree` (`mesh_util.py:124-187`) for an arbitrary host `eval_func`; cubic grids.  The bookkeeping (test
+    point selection, 8-corner min / max, block fills) runs in the HIP kernels; only `eval_func` (numpy [3, n] in, numpy
+    [n] out) is the caller's.  `coords` is the reference's [3, R, R, R] host grid, or None with `resolution` and
+    `calib_inv` given: the points of a level are then generated from their indices (a 512^3 float64 grid is 3.2 GB)."""
+    if coords is not None:
+        R = coords.shape[1]
+        if coords.shape[2] != R or coords.shape[3] != R:
+            raise NotImplementedError('cubic grids only')
+        flat = coords.reshape(3, -1)
+
+        def points_of(index):
+            return flat[:, index]
+    else:
+        if resolution is None or calib_inv is None:
+            raise ValueError('eval_grid_octree needs either the coords grid or resolution + calib_inv')
+        R = int(resolution)
+
+        def points_of(index):
+            return lattice_points(R, calib_inv, index)
     from .nets import _Ctx
     ctx = _Ctx(device)
     dev = ctx.device
@@ -165,7 +190,6 @@ def eval_grid_octree(coords, eval_func, init_resolution=64, threshold=0.05, num_
     sdf = torch.empty(R, R, R, device=dev, dtype=torch.float64)
     notproc = torch.empty(R, R, R, device=dev, dtype=torch.uint8)
     _lib.call('pifu_octree_begin', ctx.h, R, _ptr(sdf), _ptr(notproc), st)
-    flat = coords.reshape(3, -1)
     reso = R // init_resolution
     while reso > 0:
         cnt = C.c_int64(0)
@@ -175,8 +199,7 @@ def eval_grid_octree(coords, eval_func, init_resolution=64, threshold=0.05, num_
         vals = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
         if n:
             _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
-            pts = flat[:, idx[:n].cpu().numpy()]
-            out = batch_eval(pts, eval_func, num_samples=num_samples)
+            out = batch_eval(points_of(idx[:n].cpu().numpy()), eval_func, num_samples=num_samples)
             vals[:n] = torch.from_numpy(out.astype(np.float32)).to(dev)
         _lib.call('pifu_octree_commit', ctx.h, R, reso, float(threshold), _ptr(idx), _ptr(vals), n, _ptr(sdf),
                   _ptr(notproc), st)

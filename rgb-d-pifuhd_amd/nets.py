@@ -517,7 +517,7 @@ class PIFuMRNet(BasePIFuNet):
     __call__ = forward
 
     def calc_normal(self, points, calib_local, calib_global, transforms=None, labels=None, delta=0.001,
-                    fd_type='forward'):
+                    fd_type='forward', keep_pred=False):
         """`PIFuMRNet.calc_normal` (`PIFuMRNet.py:188-243`): points [1,1,3,n] -> self.nmls [1,3,n]."""
         self._check_unsupported(transforms)
         if labels is not None:
@@ -533,9 +533,11 @@ class PIFuMRNet(BasePIFuNet):
         self._sync_weights()
         calib, calib_p = _host_f32(calib_global[0])
         out = torch.empty(3, n, device=self.device, dtype=torch.float32)
-        _lib.call('pifu_calc_normal', self._ctx.h, _ptr(pts), n, calib_p, float(delta), _ptr(out),
+        pred4 = torch.empty(4 * n, device=self.device, dtype=torch.float32) if keep_pred else None
+        _lib.call('pifu_calc_normal', self._ctx.h, _ptr(pts), n, calib_p, float(delta), _ptr(out), _ptr(pred4),
                   _stream_ptr(self.device))
         self.nmls = out[None]
+        self.nml_preds = pred4.view(1, 1, n, 4) if keep_pred else None      # `pred` of PIFuMRNet.py:225, [B1, 1, N, 4]
 
     def calc_normal_chunked(self, points, calib_local, calib_global, interval=50000, delta=0.001):
         """The colour loop of `gen_mesh` (`reconstruction.py:58-70`) in one call: the same numbers as `calc_normal` on
@@ -551,7 +553,7 @@ class PIFuMRNet(BasePIFuNet):
         calib, calib_p = _host_f32(calib_global[0])
         out = torch.empty(3, n, device=self.device, dtype=torch.float32)
         _lib.call('pifu_calc_normal_chunked', self._ctx.h, _ptr(pts), n, int(interval), calib_p, float(delta), _ptr(out),
-                  _stream_ptr(self.device))
+                  None, _stream_ptr(self.device))
         self.nmls = out[None]
 
     def get_im_feat(self):

@@ -53,3 +53,24 @@ def mlp_only_nets(seed=3, mlp_std=0.16):
     synth.mlp_keys('netG.mlp', oc.mlp_dim, oc.mlp_res_layers, oc.mlp_norm, spec)
     synth.mlp_keys('mlp', of.mlp_dim, of.mlp_res_layers, of.mlp_norm, spec)
     return synth.name_seeded_state_dict(spec, seed=seed, mlp_std=mlp_std, perturb=True), oc, of
+
+
+def calib_variant(tag):
+    """Non-trivial calibration matrices [1,4,4] (float32) for the parity tests.  'scale_shift': zoom 1.25 with a
+    translation - the projected (x, y) of a lattice column still does not depend on k, so column sharing stays on and the
+    translation term of `orthogonal` is exercised.  'rot_y': 20 degrees about the y axis with zoom 1.1 - x depends on z,
+    so lattice sources take the per-point path."""
+    import math
+    c = torch.eye(4)
+    if tag == 'scale_shift':
+        c[0, 0], c[1, 1], c[2, 2] = 1.25, -1.25, 1.25
+        c[0, 3], c[1, 3], c[2, 3] = 0.1, -0.05, 0.07
+    elif tag == 'rot_y':
+        a, zoom = math.radians(20.0), 1.1
+        c[0, 0], c[0, 2] = zoom * math.cos(a), zoom * math.sin(a)
+        c[1, 1] = -zoom
+        c[2, 0], c[2, 2] = -zoom * math.sin(a), zoom * math.cos(a)
+        c[0, 3], c[2, 3] = -0.03, 0.02
+    else:
+        raise KeyError(tag)
+    return c[None]

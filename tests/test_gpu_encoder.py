@@ -80,3 +80,53 @@ def test_group_norm_filter_variant(golden_dir):
     out = torch.empty(1, 16, 32, 32, device='cuda')
     _lib.call('pifu_filter_fine', ctx.h, _ptr(x), 9, 64, 64, None, None, 64, 64, 1, 2, 16, 2, _ptr(out), _stream_ptr(ctx.device))
     assert _rel(out.cpu().numpy(), gold['group_filter_out']) < 2e-4
+
+
+def test_rgbd_six_channel_input(golden_dir):
+    """BASELINE configs[1] says RGB-D: 6 image channels (RGB || depth, `train.py:173-174`) through
+    `Filter(in_channels=6+6)` and `define_G(6, ...)` (SURVEY C-7), against goldens from the reference's parametric
+    constructors; then a query on the resulting maps."""
+    from helpers import calib_tensor, seeded_points
+    from pifuhd_amd import config, nets, synth
+    gold = np.load(os.path.join(golden_dir, 'rgbd_small.npz'))
+    oc = config.coarse_opt(in_image_channels=6)
+    of = config.fine_opt(oc)
+    of.loadSizeBig = 128
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=0.16, perturb=True)
+    assert sd['netG.image_filter.conv1.weight'].shape[1] == 12 and sd['netG.netF.model.1.weight'].shape[1] == 6
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    netMR.filter_global(synth.synthetic_image(64, 6, seed=4))
+    assert _rel(netG.nmlF.cpu().numpy(), gold['nmlF']) < 1e-4
+    assert _rel(netG.nmlB.cpu().numpy(), gold['nmlB']) < 1e-4
+    assert _rel(netG.im_feat_list[0].cpu().numpy(), gold['feat_coarse']) < 2e-4
+    netMR.filter_local(synth.synthetic_image(128, 6, seed=5)[:, None])
+    assert _rel(netMR.im_feat_list[0].cpu().numpy(), gold['feat_fine_trainmode']) < 2e-4
+    netMR.query(seeded_points(14, 600), calib_tensor())
+    assert np.abs(netMR.get_preds()[0, 0].cpu().numpy() - gold['fine']).max() < 1e-4
+
+
+def test_reloading_weights_into_a_live_net_refreshes_every_derived_buffer():
+    """State dict A, filter, then state dict B into the SAME nets: the outputs must equal those of fresh nets loaded
+    with B (folded eval-mode BatchNorm scale / shift, packed conv weights and the repacked 7x7 output conv are all
+    derived caches inside the context)."""
+    from pifuhd_amd import nets, synth
+    sd_a, oc, of = golden_nets(seed=1)
+    sd_b, _, _ = golden_nets(seed=2)
+    of.loadSizeBig = 128
+    img64, img128 = synth.synthetic_image(64, 3, seed=2), synth.synthetic_image(128, 3, seed=3)
+
+    def run(netG, netMR):
+        netMR.filter_global(img64)
+        netMR.filter_local(img128[:, None])
+        return [t.clone() for t in (netG.nmlF, netG.nmlB, netG.im_feat_list[0], netMR.im_feat_list[0])]
+    netG, netMR = nets.build_nets(oc, of, sd_a, 'cuda')
+    first = run(netG, netMR)
+    netMR.load_state_dict(sd_b)
+    again = run(netG, netMR)
+    fresh = run(*nets.build_nets(oc, of, sd_b, 'cuda'))
+    assert all(torch.equal(a, b) for a, b in zip(again, fresh))
+    assert not torch.equal(first[2], again[2])
+    with pytest.raises(RuntimeError, match='Unexpected key'):
+        netMR.load_state_dict({**sd_b, 'netG.mlp.filters.9.weight': torch.zeros(1)})
+    with pytest.raises(RuntimeError, match='Missing key'):
+        netMR.load_state_dict({k: v for k, v in sd_b.items() if k != 'mlp.filters.0.bias'})

@@ -315,3 +315,109 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     good = sorted(m for m in mhz if 100.0 < m < 4000.0)
     assert good, mhz
     assert 500.0 < good[len(good) // 2] < 3000.0, mhz
+
+
+def test_lattice_slabs_at_the_far_end_of_a_1024_cube_grid():
+    """BASELINE configs[4] index range: flat lattice indices close to 2^30.  Two slabs of a 1024^3 lattice (one that ends
+    at the last point with a ragged final chunk, one in the middle that starts inside a column) against the CPU oracle
+    evaluated on the same flat indices."""
+    import ctypes as C
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, mesh_util, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    sd, oc, of = mlp_only_nets()
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    netMR = nets.PIFuMRNet(of, netG)
+    netG.eval()
+    netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}
+    netG._push_weights()
+    netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}
+    netMR._push_weights()
+    fc, ff = seeded_features(23, hc=128, hf=512)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib_t = calib_tensor()
+    calib, cinv = mesh_util.calib_pair(calib_t)
+    R, chunk = 1024, 5000
+    res = (C.c_int32 * 3)(R, R, R)
+    total = R ** 3
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    for first, count in ((total - 2 * chunk - 1234, 2 * chunk + 1234), (total // 2 + 777, 3 * chunk)):
+        out = torch.empty(count, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  None, first, count, chunk, _lib.Q_FULL_COARSE, _ptr(out), _stream_ptr(netMR.device))
+        got = out.cpu().numpy()
+        with torch.no_grad():
+            for lo in range(0, count, chunk):
+                hi = min(lo + chunk, count)
+                flat = np.arange(first + lo, first + hi, dtype=np.int64)
+                pts = torch.from_numpy(O.grid_points_rect((R, R, R), cinv, flat).astype(np.float32))[None]
+                want = ref.query(pts, calib_t)[0, 0].numpy()
+                assert np.abs(got[lo:hi] - want).max() < 1e-4, (first, lo)
+
+
+def test_config3_octree_512_and_marching_cubes_match_the_reference(ctx, golden_dir):
+    """BASELINE configs[2]: a 512^3 grid with octree refinement.  The analytic noisy field goes through the device octree
+    (select / commit kernels, init_resolution 64, threshold 0.05, 5 000-point chunks); the float64 SDF must be
+    sha256-identical to the one the REFERENCE's eval_grid_octree produced (tests/golden/make_golden_r2.py), with the same
+    number of eval_func calls and points; marching cubes on it must reproduce scikit-image 0.18.3's vertex and face
+    streams (tests/golden/make_golden_mc512.py) bit for bit, and so must the serial oracle."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util
+    gold = np.load(os.path.join(golden_dir, 'octree512.npz'))
+    mcg = np.load(os.path.join(golden_dir, 'mc_oct512.npz'))
+    R = 512
+    calib_inv = np.linalg.inv(np.diag([1.0, -1.0, 1.0, 1.0]))
+    counts = []
+
+    def field(p):
+        counts.append(p.shape[1])
+        return noisy_field(p)
+    sdf = mesh_util.eval_grid_octree(None, field, init_resolution=64, threshold=0.05, num_samples=5000, resolution=R,
+                                     calib_inv=calib_inv)
+    assert [len(counts), int(np.sum(counts))] == list(gold['chunks_total'])
+    assert hashlib.sha256(np.array(counts, dtype=np.int64).tobytes()).digest() == gold['chunks_sha'].tobytes()
+    assert np.array_equal(sdf[::16, ::16, ::16], gold['sub'])
+    assert hashlib.sha256(sdf.tobytes()).digest() == gold['sha'].tobytes()
+    v, f = _mc(ctx, sdf)
+    assert [len(v), len(f)] == list(mcg['nv_nf'])
+    assert np.array_equal(f[::997], mcg['f_sub']) and np.array_equal(v[::997].view(np.uint32), mcg['v_sub'].view(np.uint32))
+    assert hashlib.sha256(f.tobytes()).digest() == mcg['f_sha'].tobytes()
+    assert hashlib.sha256(v.tobytes()).digest() == mcg['v_sha'].tobytes()
+    vr, fr = O.marching_cubes_lewiner(sdf, 0.5)            # the checker agrees with scikit-image at this size too
+    assert _same(v, f, vr, fr)
+
+
+@pytest.mark.parametrize('tag', ['scale_shift', 'rot_y'])
+def test_dense_grid_with_nontrivial_calibrations(golden_dir, tag):
+    """reconstruction() with a zoom + translation calib (lattice columns still share their image coordinates: the
+    column-sharing and depth-walk path) and with a rotation about y (they do not: per-point path): the SDF must match the
+    reference's, marching cubes on it the oracle's, and the vertex back-transform the reference's float64 formula with
+    the float32 inverse."""
+    from oracle import pifu_oracle as O
+    from helpers import calib_variant
+    from pifuhd_amd import mesh_util, nets
+    gold = np.load(os.path.join(golden_dir, 'calib_variants.npz'))
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(9)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = calib_variant(tag)
+    res = mesh_util.reconstruction(netMR, 'cuda', calib, 32, None, None, 0.5, use_octree=False, num_samples=5000,
+                                   return_sdf=True)
+    assert res != -1
+    verts, faces, _, _, sdf = res
+    sdf = sdf.cpu().numpy()
+    assert np.abs(sdf - gold[f'{tag}_dense32_sdf_f32']).max() < 1e-4
+    vr, fr = O.marching_cubes_lewiner(sdf, 0.5)
+    c32 = calib[0].numpy()
+    cinv = np.linalg.inv(c32)                               # float32, as the reference inverts it (mesh_util.py:61-62)
+    mat = np.eye(4)
+    mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / 32
+    mat[0:3, 3] = -1.0
+    tm = np.matmul(cinv, mat)
+    want_v = (np.matmul(tm[:3, :3], vr.T.astype(np.float32)) + tm[:3, 3:4]).T
+    assert np.array_equal(verts, want_v)
+    assert np.array_equal(faces, fr[:, ::-1] if np.linalg.det(tm[:3, :3]) < 0 else fr)

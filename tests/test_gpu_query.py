@@ -334,3 +334,74 @@ def test_default_gemm_is_bit_identical_to_its_predecessors():
     for variant in ('28', '4'):
         assert np.array_equal(product[0], outs[variant][0]), variant
         assert np.array_equal(product[1], outs[variant][1]), variant
+
+
+def test_calc_normal_values_at_the_gen_mesh_batch_size(golden_dir):
+    """calc_normal as gen_mesh calls it: 50 000 vertices = ONE GroupNorm batch of 200 000 rows (`reconstruction.py:61-68`,
+    `PIFuMRNet.py:211-230`), 128^2 / 512^2 feature maps.  The quantity the kernels compute - the 4n unmasked occupancies of
+    [p, p+dx, p+dy, p+dz] - is compared by VALUE: against the reference's own `pred` tensor (strided golden) and against
+    the oracle on all 200 000 points, at the 1e-4 of every other query; the normals are then checked by angle."""
+    from oracle import pifu_oracle as O
+    gold = np.load(os.path.join(golden_dir, 'normal_batch.npz'))
+    n = int(gold['n'][0])
+    netG, netMR, sd, oc, of = _build()
+    fc, ff = seeded_features(31, hc=128, hf=512)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = calib_tensor()
+    pts = seeded_points(41, n, lim=0.95)
+    netMR.calc_normal(pts[:, None], calib[:, None], calib, keep_pred=True)
+    pred4 = netMR.nml_preds.reshape(-1).cpu().numpy()
+    assert pred4.shape == (4 * n,)
+    assert np.abs(pred4[::7] - gold['pred4_sub']).max() < TOL
+    assert np.abs(pred4[:4096] - gold['pred4_head']).max() < TOL
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    stack = [pts.clone() for _ in range(4)]
+    for a in range(3):
+        stack[a + 1][:, a, :] += 0.001
+    pts_all = torch.stack(stack, 3).reshape(1, 3, 4 * n)
+    with torch.no_grad():
+        want = ref.query(pts_all, calib, mask_fine=False)[0, 0].numpy()
+    assert np.abs(pred4 - want).max() < TOL
+    # secondary: direction of the differences (delta = 1e-3 amplifies fp32 noise ~1e3x)
+    nm = netMR.nmls[0].cpu().numpy()
+    cos = (nm[:, ::50] * gold['nml_sub']).sum(0)
+    assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.9
+    # the chunked entry point on the same vertices is the same single batch
+    netMR.calc_normal_chunked(pts[:, None], calib[:, None], calib, interval=n)
+    assert torch.equal(netMR.nmls[0].cpu(), torch.from_numpy(nm))
+
+
+@pytest.mark.parametrize('tag', ['scale_shift', 'rot_y'])
+def test_query_with_nontrivial_calibrations(golden_dir, tag):
+    """`orthogonal` with a non-zero translation and off-diagonal rotation terms (`BasePIFuNet.py:25-43`): explicit points
+    and calc_normal against goldens from the imported reference; lattice evaluation with and without column sharing
+    against each other (the gate of the column path must follow the calib)."""
+    import ctypes as C
+    from helpers import calib_variant
+    from pifuhd_amd import _lib, mesh_util
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    gold = np.load(os.path.join(golden_dir, 'calib_variants.npz'))
+    netG, netMR, *_ = _build(feat_seed=9)
+    calib = calib_variant(tag)
+    netMR.query(seeded_points(12, 900, lim=1.1), calib)
+    fine = netMR.get_preds()[0, 0].cpu().numpy()
+    assert np.abs(fine - gold[f'{tag}_fine']).max() < TOL
+    assert np.abs(netG.preds[0, 0].cpu().numpy() - gold[f'{tag}_coarse']).max() < TOL
+    assert np.array_equal(fine == 0, gold[f'{tag}_fine'] == 0)
+    netMR.calc_normal(seeded_points(13, 200, lim=0.8)[:, None], calib[:, None], calib)
+    cos = (netMR.nmls[0].cpu().numpy() * gold[f'{tag}_nml']).sum(0)
+    assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.9
+    c32, cinv = mesh_util.calib_pair(calib)
+    res = (C.c_int32 * 3)(24, 20, 40)
+    total = 24 * 20 * 40
+    outs = []
+    for flags in (_lib.Q_FULL_COARSE, _lib.Q_FULL_COARSE | _lib.Q_NO_COLUMN_SHARING):
+        lat = torch.empty(total, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), c32.ctypes.data_as(C.c_void_p),
+                  None, 0, total, 1300, flags, _ptr(lat), _stream_ptr(netMR.device))
+        outs.append(lat.cpu().numpy())
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5
+    if tag == 'rot_y':
+        assert np.array_equal(outs[0], outs[1])             # x depends on z: both runs take the per-point path
