@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 #ifdef PIFU_LAB
 // lab builds only (tools/lab): the predecessors of k_mlp_gemm_tri (bit-identity A/B) and the rejected schedules
 #include "gemm_predecessors.inc"
+#include "gemm_dma.inc"
 #ifdef PIFU_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
 #endif
@@ -769,6 +770,15 @@ __device__ __forceinline__ double lattice_dot(double gx, double gy, double gz, c
     return __fma_rn(1.0, m[3], __fma_rn(gz, m[2], __fma_rn(gy, m[1], __dmul_rn(gx, m[0]))));
 }
 
+// One row of orthogonal(): trans + rot @ p (`torch.baddbmm`, BasePIFuNet.py:41) in the order the reference's CPU BLAS
+// evaluates it - products accumulated over k by FMA starting from the first product, translation added last.  The order
+// only matters for points that re-project onto the box boundary (the in-box masks compare with -1 and 1): with this one
+// the masks of the reference's goldens are reproduced for rotated calibrations too.
+__device__ __forceinline__ float ortho_row(const float *k, float px, float py, float pz)
+{
+    return __fadd_rn(fmaf(k[2], pz, fmaf(k[1], py, __fmul_rn(k[0], px))), k[3]);
+}
+
 __device__ __forceinline__ void bilinear_setup(float u, float v, int W, int H, int (&off)[4], float (&wt)[4])
 {
     // grid_sample(align_corners=True, padding zeros) as used by index() (BasePIFuNet.py:22)
@@ -827,11 +837,8 @@ __global__ void k_sample(const SampleArgs a)
         py = (float)lattice_dot(gx, gy, gz, m + 4);
         pz = (float)lattice_dot(gx, gy, gz, m + 8);
     }
-    // orthogonal(): xyz = R p + t (BasePIFuNet.py:25-43)
-    const float *k = a.calib;
-    const float x = fmaf(k[2], pz, fmaf(k[1], py, fmaf(k[0], px, k[3])));
-    const float y = fmaf(k[6], pz, fmaf(k[5], py, fmaf(k[4], px, k[7])));
-    const float z = fmaf(k[10], pz, fmaf(k[9], py, fmaf(k[8], px, k[11])));
+    const float *k = a.calib;      // orthogonal(): xyz = R p + t (BasePIFuNet.py:25-43)
+    const float x = ortho_row(k, px, py, pz), y = ortho_row(k + 4, px, py, pz), z = ortho_row(k + 8, px, py, pz);
     const bool in_xy = x >= -1.f && x <= 1.f && y >= -1.f && y <= 1.f;
     const bool in_xyz = in_xy && z >= -1.f && z <= 1.f;
     if (lane == 0) a.mask[row] = (uint8_t)((in_xyz ? 1 : 0) | (in_xy ? 2 : 0));
@@ -895,9 +902,7 @@ __global__ void k_sample_col(const SampleArgs a, float *zf, int *colidx, int64_t
     const float py = (float)lattice_dot(gx, gy, gz, m + 4);
     const float pz = (float)lattice_dot(gx, gy, gz, m + 8);
     const float *k = a.calib;
-    const float x = fmaf(k[2], pz, fmaf(k[1], py, fmaf(k[0], px, k[3])));
-    const float y = fmaf(k[6], pz, fmaf(k[5], py, fmaf(k[4], px, k[7])));
-    const float z = fmaf(k[10], pz, fmaf(k[9], py, fmaf(k[8], px, k[11])));
+    const float x = ortho_row(k, px, py, pz), y = ortho_row(k + 4, px, py, pz), z = ortho_row(k + 8, px, py, pz);
     const bool in_xy = x >= -1.f && x <= 1.f && y >= -1.f && y <= 1.f;
     const bool in_xyz = in_xy && z >= -1.f && z <= 1.f;
     a.mask[row] = (uint8_t)((in_xyz ? 1 : 0) | (in_xy ? 2 : 0));

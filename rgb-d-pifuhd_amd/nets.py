@@ -189,8 +189,8 @@ class PIFuNetwNML(BasePIFuNet):
         super().__init__(projection_mode)
         self.name = 'hg_pifu'
         self.opt = opt
-        self._ctx = _Ctx(device)
-        self.device = self._ctx.device
+        self._ctx_obj = _Ctx(device)
+        self.device = self._ctx_obj.device
         self._sd = None
         self.im_feat_list = []
         self.normx = None
@@ -202,6 +202,14 @@ class PIFuNetwNML(BasePIFuNet):
         self.netB = 'netB' if getattr(opt, 'use_back_normal', False) else None
         self._last_n = 0
         self._dirty, self._pushed_code = True, None
+
+    @property
+    def _ctx(self):
+        """The library context, with pending weight changes (load_state_dict, train / eval) uploaded first: whoever calls
+        the C ABI through it sees the current weights."""
+        if self._sd is not None:
+            self._sync_weights()
+        return self._ctx_obj
 
     # -- parameters --------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True, _prefix='', _check=True):
@@ -243,10 +251,10 @@ class PIFuNetwNML(BasePIFuNet):
         o = self.opt
         # eval mode on the reconstruction path (reconstruction.py:288-289): running stats for 'batch'
         code = _mlp_norm_code(o.mlp_norm, self.training)
-        _push_mlp(self._ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers),
-                  int(o.merge_layer), code)
-        _lib.call('pifu_set_depth_normalizer', self._ctx.h, float(o.loadSize // 2), float(o.z_size))
-        _push_encoder_params(self._ctx, self._sd, '')
+        ctx = self._ctx_obj
+        _push_mlp(ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), int(o.merge_layer), code)
+        _lib.call('pifu_set_depth_normalizer', ctx.h, float(o.loadSize // 2), float(o.z_size))
+        _push_encoder_params(ctx, self._sd, '')
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):
@@ -342,7 +350,6 @@ class PIFuMRNet(BasePIFuNet):
         self.w = None
         self.gamma = None
         self.labels_nml = None
-        self._ctx = netG._ctx
         self.device = netG.device
         self._sd = None
         self.im_feat_list = []
@@ -351,6 +358,13 @@ class PIFuMRNet(BasePIFuNet):
         self.normx = None
         self.training = True          # a freshly constructed module is in train mode (SURVEY C-2)
         self._dirty, self._pushed_code = True, None
+
+    @property
+    def _ctx(self):
+        """The context shared with netG, with the pending weight changes of both levels uploaded first."""
+        if self._sd is not None:
+            self._sync_weights()
+        return self.netG._ctx_obj
 
     def train(self, mode=True):
         """`PIFuMRNet.train` (`PIFuMRNet.py:59-69`): netG is forced to eval unless train_full_pifu."""
@@ -383,8 +397,9 @@ class PIFuMRNet(BasePIFuNet):
         o = self.opt
         code = _mlp_norm_code(o.mlp_norm, self.training)      # train mode => per-chunk batch statistics (C-2)
         self.netG._sync_weights()                               # the fine MLP is defined against the coarse one
-        _push_mlp(self._ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
-        _push_encoder_params(self._ctx, self._sd, 'fine.')
+        ctx = self.netG._ctx_obj
+        _push_mlp(ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
+        _push_encoder_params(ctx, self._sd, 'fine.')
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):
