@@ -29,6 +29,20 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_QUERY = 2916098            # coarse MLP 2,100,738 + fine MLP 815,360
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_INFINITY_CACHE_GATHER_GBS = 8600.0   # MI355X_MICROARCH.md "Indexed rows": uniformly random rows of a 38 MB table
+
+
+def read_prof(_lib, h, which, reset=1):
+    """(ms, launches, work) of one profiling slot of the library context."""
+    ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+    _lib.call('pifu_profile_read', h, which, C.byref(ms), C.byref(n), C.byref(w), reset)
+    return ms.value, n.value, w.value
+
+
+def reset_prof(_lib, h):
+    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC):
+        _lib.call('pifu_profile_read', h, which, None, None, None, 1)
 
 
 def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
@@ -98,6 +112,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-genmesh', action='store_true')
     ap.add_argument('--no-lean-pass', action='store_true', help='skip the extra pass without the unread coarse tail')
+    ap.add_argument('--dist-selftest', action='store_true',
+                    help='functional check, never a measurement: initialise the process group (backend nccl = RCCL) even with ONE '
+                         'rank and run every collective of the sharded path (all-gather of the field, of the colours, barrier)')
+    ap.add_argument('--no-canonical', action='store_true', help='skip the extra canonical per-point pass (no column sharing)')
+    ap.add_argument('--canonical-steps', type=int, default=2)
+    ap.add_argument('--no-cpu-genmesh', action='store_true', help='skip the CPU (oracle) gen_mesh baseline at --cpu-genmesh-res')
+    ap.add_argument('--cpu-genmesh-res', type=int, default=128)
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
@@ -129,12 +150,17 @@ def main():
     one_gpu_test = os.environ.get('PIFU_BENCH_ONE_GPU') == '1'
     dev = torch.device('cuda', 0 if one_gpu_test else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         if one_gpu_test:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+        if args.dist_selftest:
+            pdist.ALWAYS_COLLECTIVE = True
 
     # ---- model + inputs (outside the timed region) ---------------------------------------------------
     oc = config.coarse_opt()
@@ -174,9 +200,11 @@ def main():
     def step():
         return pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, flags)
 
+    grouped = world > 1 or args.dist_selftest       # a process group exists: barriers / reductions / sharded gen_mesh run
+
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -184,7 +212,7 @@ def main():
         step()
     fence()
     log('warm-up done')
-    _lib.call('pifu_profile_read', h, None, None, None, 1)
+    reset_prof(_lib, h)
     _lib.call('pifu_profile_enable', h, 1)
 
     def clock_probe():
@@ -208,11 +236,11 @@ def main():
     mhz = sorted(m for m in mhz if 100.0 < m < 4000.0)      # an XCD whose counter was reset by power gating reads garbage: dropped
     eff_mhz = mhz[len(mhz) // 2] if mhz else None            # median over the XCDs
     _lib.call('pifu_profile_enable', h, 0)
-    gemm_ms, gemm_n, gemm_flops = C.c_double(0), C.c_int64(0), C.c_double(0)
-    _lib.call('pifu_profile_read', h, C.byref(gemm_ms), C.byref(gemm_n), C.byref(gemm_flops), 1)
+    g_ms, g_n, g_fl = read_prof(_lib, h, _lib.PROF_GEMM)
+    gemm_ms, gemm_n, gemm_flops = C.c_double(g_ms), C.c_int64(g_n), C.c_double(g_fl)
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -221,7 +249,7 @@ def main():
     # ---- second half of the metric at N > 1: one subject's 512^3 gen_mesh sharded over the ranks, and N independent
     # subjects (one per GPU, BASELINE configs[3]); every rank takes part, rank 0 reports
     multi = None
-    if world > 1 and not args.no_genmesh and args.features == 'filter':
+    if grouped and not args.no_genmesh and args.features == 'filter':
         multi = genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log)
     if rank != 0:
         dist.barrier()
@@ -229,11 +257,15 @@ def main():
         return
 
     achieved = gemm_flops.value / (gemm_ms.value * 1e-3) / 1e12 if gemm_ms.value > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc is its own run):
+    # the figure comes from the committed profile of an EARLIER run of this command and is labelled as such
+    traffic, traffic_src, prof_json = None, None, {}
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('k_mlp_gemm_hbm_bytes_per_launch')
+            prof_json = json.load(open(tpath))
+            traffic = prof_json.get('k_mlp_gemm_hbm_bytes_per_launch')
+            traffic_src = 'profiles/traffic.json (rocprofv3 --pmc pass of an earlier run of this command, not this run)'
         except Exception:
             traffic = None
     out = {
@@ -257,6 +289,7 @@ def main():
         'roofline': {
             'kernel': 'k_mlp_gemm_tri', 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': traffic,
+            'traffic_source': traffic_src,
             'launches': gemm_n.value, 'avg_launch_ms': round(gemm_ms.value / max(gemm_n.value, 1), 4),
             'alg_gflop_per_launch': round(gemm_flops.value / max(gemm_n.value, 1) / 1e9, 3),
             'gemm_time_share_of_step': round(gemm_ms.value * 1e-3 / elapsed, 4),
@@ -265,6 +298,62 @@ def main():
             'frac_at_measured_clock': round(achieved / (PEAK_FP32_MATRIX_TFLOPS * eff_mhz / 2400.0), 4) if eff_mhz else None,
         },
     }
+
+    # ---- the canonical per-point evaluation (no column sharing, no depth walk: every one of the 2 916 098 FLOP of a query
+    # is executed, and the per-point sampler k_sample runs on every point): reported beside the headline, never as `value`
+    secondary = []
+    if world == 1 and not args.no_canonical and not args.no_column_sharing:
+        try:
+            cflags = flags | _lib.Q_NO_COLUMN_SHARING
+            pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, cflags)
+            fence()
+            reset_prof(_lib, h)
+            _lib.call('pifu_profile_enable', h, 1)
+            c0 = time.perf_counter()
+            for _ in range(args.canonical_steps):
+                field_c = pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, cflags)
+            fence()
+            c_el = time.perf_counter() - c0
+            _lib.call('pifu_profile_enable', h, 0)
+            cg_ms, cg_n, cg_fl = read_prof(_lib, h, _lib.PROF_GEMM)
+            cs_ms, cs_n, cs_by = read_prof(_lib, h, _lib.PROF_SAMPLER)
+            c_val = total * args.canonical_steps / c_el / 1e6
+            c_gemm = cg_fl / (cg_ms * 1e-3) / 1e12 if cg_ms > 0 else 0.0
+            out['canonical_path'] = {
+                'value': round(c_val, 3), 'unit': 'Mqueries/s', 'steps': args.canonical_steps,
+                'ms_per_step': round(c_el / max(args.canonical_steps, 1) * 1e3, 3),
+                'flop_per_query_executed': FLOP_PER_QUERY,
+                'whole_path_tflops': round(c_val * 1e6 * FLOP_PER_QUERY / 1e12, 2),
+                'whole_path_frac_of_fp32_matrix_peak': round(c_val * 1e6 * FLOP_PER_QUERY / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                'gemm_roofline': {'kernel': 'k_mlp_gemm_tri', 'achieved': round(c_gemm, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': round(c_gemm / PEAK_FP32_MATRIX_TFLOPS, 4), 'launches': cg_n},
+                'max_abs_diff_vs_headline_field': float((field_c - field).abs().max().item())}
+            log(f"canonical per-point path: {c_val:.1f} Mq/s, GEMM {c_gemm:.1f} TFLOP/s")
+            if cs_ms > 0:
+                # the two feature maps (coarse 128^2 x 256 + fine 512^2 x 16 fp32 = 33.6 MB) stay in the 256 MB Infinity
+                # Cache, so the gathers are priced against the cache-gather rate of the guide, not against HBM; what HBM
+                # must move is the MLP input rows written (and the maps once)
+                rows_bytes = float(cs_by)
+                per_launch = rows_bytes / max(cs_n, 1)
+                gather_share = 4.0 * (256 + 16) * 4.0 / (4.0 * (256 + 16) * 4.0 + (288 + 32) * 4.0)
+                ach = rows_bytes / (cs_ms * 1e-3) / 1e9
+                map_bytes = float(sum(t.numel() * 4 for t in (netG.im_feat_list[-1], netMR.im_feat_list[-1])))
+                compulsory = per_launch * (1.0 - gather_share) + map_bytes
+                pmc = prof_json.get('k_sample_hbm_bytes_per_launch')
+                secondary.append({
+                    'kernel': 'k_sample (per-point sampler of the canonical path)', 'bound': 'infinity_cache',
+                    'achieved': round(ach, 1), 'peak': PEAK_INFINITY_CACHE_GATHER_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / PEAK_INFINITY_CACHE_GATHER_GBS, 4),
+                    'peak_source': 'MI355X_MICROARCH.md, indexed rows of a 38 MB table served by the Infinity Cache',
+                    'launches': cs_n, 'avg_launch_ms': round(cs_ms / max(cs_n, 1), 4),
+                    'alg_bytes_per_launch': round(per_launch), 'gather_share_of_alg_bytes': round(gather_share, 3),
+                    'compulsory_hbm_bytes_per_launch': round(compulsory),
+                    'alg_over_compulsory': round(per_launch / compulsory, 2),
+                    'traffic': pmc, 'traffic_source': traffic_src if pmc else None})
+        except Exception as e:      # the metric line must still be printed
+            out['canonical_path'] = {'error': repr(e)}
+        finally:
+            _lib.call('pifu_profile_enable', h, 0)
 
     # ---- the same lattice without the coarse MLP's tail (layers 3-4 + sigmoid produce netG.preds, which nothing on the
     # gen_mesh path reads: reconstruction() runs this way); reported beside the headline, never as `value`
@@ -298,7 +387,7 @@ def main():
             try:
                 step()
                 fence()
-                _lib.call('pifu_profile_read', h, None, None, None, 1)
+                reset_prof(_lib, h)
                 _lib.call('pifu_profile_enable', h, 1)
                 s0 = time.perf_counter()
                 field_split = None
@@ -307,8 +396,8 @@ def main():
                 fence()
                 s_el = time.perf_counter() - s0
                 _lib.call('pifu_profile_enable', h, 0)
-                sm, sn, sf = C.c_double(0), C.c_int64(0), C.c_double(0)
-                _lib.call('pifu_profile_read', h, C.byref(sm), C.byref(sn), C.byref(sf), 1)
+                s_ms, s_n, s_fl = read_prof(_lib, h, _lib.PROF_GEMM)
+                sm, sn, sf = C.c_double(s_ms), C.c_int64(s_n), C.c_double(s_fl)
                 split_fields[key] = field_split
                 out[key] = {'arithmetic': arith[mode],
                             'value': round(total * args.steps / s_el / 1e6, 3), 'unit': 'Mqueries/s',
@@ -365,22 +454,123 @@ def main():
     # ---- second half of the metric: end-to-end gen_mesh wall time (single GPU) ---------------------------
     if world == 1 and not args.no_genmesh and args.features == 'filter':
         import tempfile
-        from pifuhd_amd import reconstruction as recon
+        from pifuhd_amd import mesh_util, reconstruction as recon
         with tempfile.TemporaryDirectory() as td:
             timings = {}
             try:
                 recon.gen_mesh(128, netMR, dev, data, os.path.join(td, 'warm.obj'))            # warm-up (allocations)
                 log('gen_mesh warm-up done')
                 torch.cuda.synchronize(dev)
+                reset_prof(_lib, h)
+                _lib.call('pifu_profile_enable', h, 1)
                 recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'mesh.obj'), timings=timings)
+                _lib.call('pifu_profile_enable', h, 0)
+                mc_ms, mc_n, mc_bytes = read_prof(_lib, h, _lib.PROF_MC)
                 out['gen_mesh'] = {'resolution': args.genmesh_res, 'use_octree': True,
                                    **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()}}
+                if mc_ms > 0:
+                    ach = mc_bytes / (mc_ms * 1e-3) / 1e9
+                    secondary.append({
+                        'kernel': 'marching cubes (k_mc_bricks/minmax/count/scan + k_mc_verts/faces) of the gen_mesh run',
+                        'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(ach / PEAK_HBM_GBS, 4), 'ms': round(mc_ms, 3),
+                        'alg_bytes': round(mc_bytes), 'alg_bytes_definition': 'one pass over the float64 SDF (R^3 x 8 B) + 12 B per '
+                        'vertex and per face written', 'traffic': None})
+                # parity of the mesh the timed run produced: the same grid once more (not timed), marching cubes on a 128^3
+                # crop around the surface on the GPU and on the serial oracle - vertices and faces must agree bit for bit
+                r = mesh_util.reconstruction(netMR, dev, calib, args.genmesh_res, None, None, 0.5, use_octree=True,
+                                             num_samples=5000, return_sdf=True)
+                if r != -1:
+                    from oracle import pifu_oracle as O
+                    verts_r, faces_r, _, _, sdf_d = r
+                    same_mesh = len(verts_r) == timings.get('n_verts') and len(faces_r) == timings.get('n_faces')
+                    inside = (sdf_d > 0.5).nonzero()
+                    ctr = [int(inside[:, k].float().mean().item()) for k in range(3)] if len(inside) else [args.genmesh_res // 2] * 3
+                    cw = min(128, args.genmesh_res)
+                    lo = [min(max(c - cw // 2, 0), args.genmesh_res - cw) for c in ctr]
+                    crop = sdf_d[lo[0]:lo[0] + cw, lo[1]:lo[1] + cw, lo[2]:lo[2] + cw].contiguous()
+                    gv, gf = mesh_util.marching_cubes_device(netMR._ctx, crop, 0.5)
+                    ov, of_ = O.marching_cubes_lewiner(crop.cpu().numpy(), 0.5)
+                    out['gen_mesh']['mc_check'] = {
+                        'crop': [lo, cw], 'n_verts': int(len(gv)), 'n_faces': int(len(gf)),
+                        'faces_bit_exact_vs_oracle': bool(np.array_equal(gf.cpu().numpy(), of_)),
+                        'verts_bit_exact_vs_oracle': bool(np.array_equal(gv.cpu().numpy().view(np.uint32), ov.view(np.uint32))),
+                        'rerun_reproduces_mesh_size': bool(same_mesh)}
+                    log(f"mc check: {out['gen_mesh']['mc_check']}")
             except Exception as e:      # the metric line must still be printed
                 out['gen_mesh'] = {'error': repr(e)}
+            finally:
+                _lib.call('pifu_profile_enable', h, 0)
+
+            # ---- CPU baseline for the second half of the metric: the oracle's gen_mesh phases (octree grid evaluation,
+            # serial Lewiner marching cubes, the calc_normal colour loop) at a resolution the host finishes in seconds,
+            # with the GPU run at the SAME resolution beside it.  The encoders are left out on the CPU side (minutes there):
+            # the oracle uses the feature maps of the GPU filter pass, which the sample text says.
+            if not args.no_cpu_genmesh and not args.no_cpu_baseline:
+                try:
+                    from oracle import pifu_oracle as O
+                    Rc = args.cpu_genmesh_res
+                    ncores = min(os.cpu_count() or 1, args.cpu_threads)
+                    torch.set_num_threads(ncores)
+                    ref = O.OracleNets(sd, oc, of, fine_training=True)
+                    ref.feat_coarse = netG.im_feat_list[-1].cpu()
+                    ref.feat_fine = netMR.im_feat_list[-1].cpu()
+                    calib_np = calib[0].numpy().astype(np.float64)
+
+                    def field(pts):
+                        with torch.no_grad():
+                            return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib)[0, 0].numpy()
+                    stats = []
+                    c0 = time.perf_counter()
+                    sdf_c = O.eval_grid_octree(Rc, np.linalg.inv(calib_np), field, 5000, stats=stats)
+                    c1 = time.perf_counter()
+                    cv, cf = O.marching_cubes_lewiner(sdf_c, 0.5)
+                    c2 = time.perf_counter()
+                    vt = torch.from_numpy(((cv.astype(np.float64) * (2.0 / Rc) - 1.0) * np.array([1.0, -1.0, 1.0])).T.astype(np.float32))[None]
+                    spans = recon._normal_spans(len(cv))
+                    done_v, n_spans = 0, 0
+                    with torch.no_grad():
+                        for (l, r_) in spans:
+                            if r_ <= l:
+                                continue
+                            ref.calc_normal(vt[:, :, l:r_], calib)
+                            done_v += r_ - l
+                            n_spans += 1
+                            if time.perf_counter() - c2 > args.cpu_seconds:
+                                break
+                    c3 = time.perf_counter()
+                    normals_s = (c3 - c2) * (len(cv) / max(done_v, 1))          # extrapolated when the loop was cut short
+                    gt = {}
+                    recon.gen_mesh(Rc, netMR, dev, data, os.path.join(td, 'same_res.obj'), timings=gt)
+                    out['cpu_baseline_gen_mesh'] = {
+                        'resolution': Rc, 'kind': 'port', 'cores': ncores, 'unit': 's',
+                        'value': round((c1 - c0) + (c2 - c1) + normals_s, 3),
+                        'reconstruction_s': round(c2 - c0, 3), 'grid_eval_s': round(c1 - c0, 3), 'marching_cubes_s': round(c2 - c1, 3),
+                        'normals_s': round(normals_s, 3), 'normals_measured_on': f'{n_spans} of {len(spans)} calc_normal calls '
+                        f'({done_v} of {len(cv)} vertices), scaled to all',
+                        'points_evaluated': int(sum(n for _, n in stats)), 'n_verts': int(len(cv)), 'n_faces': int(len(cf)),
+                        'sample': f'oracle (oracle/pifu_oracle.py + oracle/mc_lewiner.c) octree grid + marching cubes + colour loop at '
+                                  f'{Rc}^3 on {ncores} of {os.cpu_count()} host threads; encoders excluded (feature maps taken from the GPU pass); '
+                                  f'no OBJ write',
+                        'gpu_same_resolution': {'total_s': round(gt.get('total_s', float('nan')), 4),
+                                                'filter_s': round(gt.get('filter_s', float('nan')), 4),
+                                                'reconstruction_s': round(gt.get('reconstruction_s', float('nan')), 4),
+                                                'normals_s': round(gt.get('normals_s', float('nan')), 4),
+                                                'obj_s': round(gt.get('obj_s', float('nan')), 4),
+                                                'n_verts': gt.get('n_verts'), 'n_faces': gt.get('n_faces')}}
+                    log(f"cpu gen_mesh baseline at {Rc}^3: {out['cpu_baseline_gen_mesh']['value']} s; GPU {gt.get('total_s'):.3f} s")
+                except Exception as e:
+                    out['cpu_baseline_gen_mesh'] = {'error': repr(e)}
+    if secondary:
+        out['roofline_secondary'] = secondary
     if multi is not None:
         out['gen_mesh'] = multi
+    if args.dist_selftest:
+        out['dist_selftest'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                                'collectives': 'all_gather_into_tensor (field, colours), all_reduce(MAX), barrier',
+                                'note': 'functional check of the multi-rank code path on one rank; not a measurement'}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -137,7 +137,10 @@ int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_i
 /* state: sdf float64 [R^3] and notprocessed uint8 [R^3], both device, caller-owned. */
 int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *notprocessed, pifu_stream stream);
 /* Ordered (C-order) compaction of lattice(reso) & notprocessed into index_out (device int64, capacity
- * cap); *count_host receives the number of test points.  Synchronises the stream. */
+ * cap); *count_host receives the number of test points.  Call pattern per level: once with index_out = NULL (counting
+ * pass; synchronises the stream ONCE to return the count), then with a buffer of that capacity (fill pass: reuses the
+ * block counts of the counting pass, launches the compaction only and does not synchronise).  A fill call that does not
+ * follow the counting call of the same level recounts and synchronises. */
 int pifu_octree_select(pifu_ctx *ctx, int R, int reso, const uint8_t *notprocessed,
                        int64_t *index_out, int64_t cap, int64_t *count_host, pifu_stream stream);
 /* Scatter the evaluated values, clear notprocessed there, then (if reso > 1) the 8-corner min/max test
@@ -197,11 +200,16 @@ int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const
 int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, int64_t n, const float *gamma,
                   float fixed_gamma, const float *w, int w_per_element, int brock, float *out, pifu_stream stream);
 
-/* ---- measurement hook (bench.py / profiles): HIP-event timing of every MLP GEMM launch (k_mlp_gemm_tri) on its own stream --
- * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms),
- * number of launches and the ALGORITHMIC FLOPs of those launches (2 * valid points * Cout * Cin). */
+/* ---- measurement hook (bench.py / profiles): HIP-event timing, on the launch stream, of the kernels bench.py prices
+ * against a roofline.  `which`: PIFU_PROF_GEMM = every MLP GEMM launch (k_mlp_gemm_tri; work = ALGORITHMIC FLOPs,
+ * 2 * valid points * Cout * Cin), PIFU_PROF_SAMPLER = every per-point k_sample launch (work = algorithmic bytes: 4 taps x
+ * channels gathered + one MLP input row written per valid point), PIFU_PROF_MC = the marching-cubes kernels of
+ * pifu_mc_count + pifu_mc_emit (two timed spans per mesh; work = one pass over the volume, n0 * n1 * n2 * sizeof(value), plus the
+ * 12-byte vertices and faces written).
+ * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms), launches, work. */
+enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2 };
 int pifu_profile_enable(pifu_ctx *ctx, int on);
-int pifu_profile_read(pifu_ctx *ctx, double *gemm_ms, int64_t *gemm_launches, double *gemm_flops, int reset);
+int pifu_profile_read(pifu_ctx *ctx, int which, double *ms, int64_t *launches, double *work, int reset);
 
 /* pifu_clock_probe synchronises the stream and returns, per XCD (8 on MI355X), the shader-clock counter (s_memtime)
  * and the constant 100 MHz real-time counter (s_memrealtime) read by one wave on that XCD: out[2 * xcd] = shader ticks,

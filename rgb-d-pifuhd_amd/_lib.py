@@ -14,6 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
+PROF_GEMM, PROF_SAMPLER, PROF_MC = 0, 1, 2
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
 
 
@@ -61,7 +62,7 @@ SIGNATURES = {
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
     'pifu_bce_loss': (_i32, [_p, _p, _p, _i32, _i64, _p, _f, _p, _i32, _i32, _p, _p]),
     'pifu_profile_enable': (_i32, [_p, _i32]),
-    'pifu_profile_read': (_i32, [_p, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
+    'pifu_profile_read': (_i32, [_p, _i32, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
     'pifu_clock_probe': (_i32, [_p, _p, _p]),
     'pifu_write_obj': (_i32, [C.c_char_p, _p, _p, _i64, _p, _i64]),
 }

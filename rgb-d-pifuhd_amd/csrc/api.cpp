@@ -134,7 +134,8 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
         if (ctx->mlp[L].colW) (void)hipFree(ctx->mlp[L].colW);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);
-    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (auto &slot : ctx->prof)
+        for (hipEvent_t e : slot.ev) (void)hipEventDestroy(e);
 #ifdef PIFU_LAB
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     if (ctx->debug_buf) (void)hipFree(ctx->debug_buf);
@@ -143,6 +144,63 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
     delete ctx;
+    return PIFU_OK;
+}
+
+int pifu_prof_begin(pifu_ctx *ctx, int slot, hipStream_t st, hipEvent_t *stop)
+{
+    *stop = nullptr;
+    if (!ctx->prof_on) return PIFU_OK;
+    pifu_ctx::ProfSlot &p = ctx->prof[slot];
+    if (p.used + 2 > p.ev.size()) {
+        hipEvent_t a0, a1;
+        // device-scope release only: a system-scope fence per event costs ~5 us of idle GPU around every timed launch
+        PIFU_HIP(hipEventCreateWithFlags(&a0, hipEventDisableSystemFence));
+        PIFU_HIP(hipEventCreateWithFlags(&a1, hipEventDisableSystemFence));
+        p.ev.push_back(a0);
+        p.ev.push_back(a1);
+    }
+    hipEvent_t e0 = p.ev[p.used];
+    *stop = p.ev[p.used + 1];
+    p.used += 2;
+    PIFU_HIP(hipEventRecord(e0, st));
+    return PIFU_OK;
+}
+
+int pifu_prof_end(pifu_ctx *ctx, int slot, hipEvent_t stop, double work, hipStream_t st)
+{
+    if (!stop) return PIFU_OK;
+    PIFU_HIP(hipEventRecord(stop, st));
+    ctx->prof[slot].work += work;
+    ctx->prof[slot].launches += 1;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_profile_enable(pifu_ctx *ctx, int on)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_profile_enable: null context");
+    ctx->prof_on = on != 0;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_profile_read(pifu_ctx *ctx, int which, double *ms_out, int64_t *launches, double *work, int reset)
+{
+    PIFU_REQUIRE(ctx && which >= 0 && which < PIFU_PROF_SLOTS, PIFU_ERR_INVALID, "pifu_profile_read: bad argument");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    PIFU_HIP(hipDeviceSynchronize());
+    pifu_ctx::ProfSlot &p = ctx->prof[which];
+    double ms = p.ms_acc;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float t = 0.f;
+        PIFU_HIP(hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]));
+        ms += t;
+    }
+    p.ms_acc = ms;
+    p.used = 0;                              // events can be recycled: their time is folded into the accumulator
+    if (ms_out) *ms_out = ms;
+    if (launches) *launches = p.launches;
+    if (work) *work = p.work;
+    if (reset) { p.ms_acc = 0.0; p.work = 0.0; p.launches = 0; }
     return PIFU_OK;
 }
 

@@ -436,6 +436,9 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     uint64_t *totals = (uint64_t *)(base + 2 * scan_bytes);
     float *mm = (float *)(base + 2 * scan_bytes + 256);
     uint8_t *brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    hipEvent_t prof_stop;
+    rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_mc_bricks, dim3((unsigned)((nbricks + 3) / 4)), dim3(256), 0, st, v, brick);
     v.brick = brick;
 
@@ -444,6 +447,9 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     hipLaunchKernelGGL(k_mc_count, dim3((unsigned)nblocks), dim3(256), 0, st, v, blk_verts, blk_tris);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, blk_verts, nblocks, totals);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, blk_tris, nblocks, totals + 1);
+    // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
+    rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
+    if (rc) return rc;
     char *pin = (char *)ctx->pinned;
     PIFU_HIP(hipMemcpyAsync(pin, totals, 16, hipMemcpyDeviceToHost, st));
     PIFU_HIP(hipMemcpyAsync(pin + 16, mm, 8, hipMemcpyDeviceToHost, st));
@@ -486,9 +492,15 @@ extern "C" int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_st
     uint64_t *blk_tris = (uint64_t *)(base + scan_bytes);
     v.brick = (const uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);      // built by pifu_mc_count for this volume
     int32_t *edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + brick_bytes);
+    hipEvent_t prof_stop;
+    int rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts, verts, edge_index);
     hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts,
                        (const uint64_t *)blk_tris, (const int32_t *)edge_index, faces);
+    // timed: the emit half; work = the vertex and face streams written (12 B each)
+    rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, 12.0 * ((double)m.nverts + (double)m.nfaces), st);
+    if (rc) return rc;
     PIFU_HIP(hipGetLastError());
     ctx->mc.valid = false;
     return PIFU_OK;

@@ -134,28 +134,40 @@ __global__ void k_f32_to_f64(const float *src, double *dst, int64_t n)
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-// count (and, when index_out != null, compact) the test points of one level
+// One level's test points.  Counting pass: per-block counts + scan into ctx->misc, ONE host synchronisation to return the
+// total (the caller sizes its index buffer from it).  Fill pass: ordered compaction from those block counts - when it follows
+// the counting pass of the same level directly (the normal call pattern) it launches the scatter kernel only, without a
+// second count or synchronisation; otherwise it recounts first.
 int octree_select_impl(pifu_ctx *ctx, int R, int reso, const uint8_t *notproc, int64_t *index_out, int64_t cap,
                        int64_t *count_host, bool count_only, hipStream_t st)
 {
     const int nl = (R + reso - 1) / reso;
     const int64_t nlat = (int64_t)nl * nl * nl;
     const int64_t nblocks = (nlat + SEL_TILE - 1) / SEL_TILE;
-    int rc = pifu_ensure(ctx->misc, (size_t)(nblocks + 2) * sizeof(uint64_t));
-    if (rc) return rc;
-    uint64_t *counts = (uint64_t *)ctx->misc.p;
-    uint64_t *total = counts + nblocks;
-    hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat, counts);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, counts, nblocks, total);
-    PIFU_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PIFU_HIP(hipStreamSynchronize(st));
-    const int64_t n = (int64_t)(*(uint64_t *)ctx->pinned);
+    pifu_ctx::SelState &sel = ctx->sel;
+    const bool cached = !count_only && sel.valid && sel.R == R && sel.reso == reso && sel.notproc == notproc;
+    if (!cached) {
+        sel.valid = false;
+        int rc = pifu_ensure(ctx->misc, (size_t)(nblocks + 2) * sizeof(uint64_t));
+        if (rc) return rc;
+        uint64_t *counts = (uint64_t *)ctx->misc.p;
+        uint64_t *total = counts + nblocks;
+        hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat, counts);
+        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, counts, nblocks, total);
+        PIFU_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PIFU_HIP(hipStreamSynchronize(st));
+        sel.n = (int64_t)(*(uint64_t *)ctx->pinned);
+        sel.R = R; sel.reso = reso; sel.notproc = notproc;
+        sel.valid = true;
+    }
+    const int64_t n = sel.n;
     *count_host = n;
     if (count_only || n == 0) return PIFU_OK;
+    sel.valid = false;                      // the counts are consumed by this fill
     PIFU_REQUIRE(index_out && cap >= n, PIFU_ERR_INVALID, "pifu_octree_select: index buffer holds %lld entries, %lld needed",
                  (long long)cap, (long long)n);
     hipLaunchKernelGGL(k_oct_scatter_index, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat,
-                       (const uint64_t *)counts, index_out);
+                       (const uint64_t *)ctx->misc.p, index_out);
     PIFU_HIP(hipGetLastError());
     return PIFU_OK;
 }
@@ -166,6 +178,7 @@ extern "C" int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *not
 {
     PIFU_REQUIRE(ctx && sdf && notprocessed && R >= 2, PIFU_ERR_INVALID, "pifu_octree_begin: bad argument");
     PIFU_HIP(hipSetDevice(ctx->device));
+    ctx->sel.valid = false;
     const int64_t n = (int64_t)R * R * R;
     hipLaunchKernelGGL(k_oct_begin, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, sdf, notprocessed, R);
     PIFU_HIP(hipGetLastError());
@@ -186,6 +199,7 @@ extern "C" int pifu_octree_commit(pifu_ctx *ctx, int R, int reso, double thresho
     PIFU_REQUIRE(ctx && sdf && notprocessed && R >= 2 && reso >= 1 && count >= 0, PIFU_ERR_INVALID, "pifu_octree_commit: bad argument");
     PIFU_REQUIRE(count == 0 || (index && values), PIFU_ERR_INVALID, "pifu_octree_commit: null index/values");
     PIFU_HIP(hipSetDevice(ctx->device));
+    ctx->sel.valid = false;
     hipStream_t st = (hipStream_t)stream;
     if (count > 0)
         hipLaunchKernelGGL(k_oct_scatter_values, dim3(blocks_for(count, 256)), dim3(256), 0, st, index, values, count, sdf, notprocessed);

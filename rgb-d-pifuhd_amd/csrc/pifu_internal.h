@@ -34,6 +34,7 @@ constexpr int PIFU_BN = 128;   // output channels per block tile
 constexpr int PIFU_BK = 32;    // K step; every K segment is padded to a multiple of it
 constexpr int PIFU_MAX_LAYERS = 8;
 constexpr int PIFU_MAX_WIDTH = 8192;  // widest MLP layer / input supported
+constexpr int PIFU_PROF_SLOTS = 3;    // PIFU_PROF_GEMM, PIFU_PROF_SAMPLER, PIFU_PROF_MC
 
 static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
@@ -107,6 +108,9 @@ struct pifu_ctx {
     McState mc;
     // octree scratch
     DevBuf oct_arena;
+    // block counts of the last pifu_octree_select count call (kept in `misc`), so that the fill call of the same level
+    // needs neither a second counting pass nor a second host synchronisation
+    struct SelState { bool valid = false; int R = 0, reso = 0; const uint8_t *notproc = nullptr; int64_t n = 0; } sel;
     // column tables of the lattice evaluation (column sharing)
     DevBuf col_arena;
     int col_enable = 1;
@@ -128,13 +132,21 @@ struct pifu_ctx {
     int precision = 0;
     struct Planes { void *hi; void *lo; size_t n; };
     std::map<const void *, Planes> bf16_planes;
+    // optional HIP-event timing of the kernels bench.py prices against a roofline (pifu_profile_*), one slot per kernel
     bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
-    size_t prof_used = 0;                 // events in use
-    double prof_flops = 0.0;              // algorithmic FLOPs of the timed launches
-    double prof_ms_acc = 0.0;             // time already folded in (events recycled)
-    int64_t prof_launches = 0;
+    struct ProfSlot {
+        std::vector<hipEvent_t> ev;       // pairs (start, stop)
+        size_t used = 0;                  // events in use
+        double work = 0.0;                // algorithmic work of the timed launches (FLOPs or bytes)
+        double ms_acc = 0.0;              // time already folded in (events recycled)
+        int64_t launches = 0;
+    } prof[PIFU_PROF_SLOTS];
 };
+
+// records the start event of a timed launch in `slot` (no-op when profiling is off: *stop = nullptr)
+int pifu_prof_begin(pifu_ctx *ctx, int slot, hipStream_t st, hipEvent_t *stop);
+// records the stop event and books the launch's algorithmic work
+int pifu_prof_end(pifu_ctx *ctx, int slot, hipEvent_t stop, double work, hipStream_t st);
 
 int pifu_ensure(DevBuf &b, size_t bytes);   // grow-only hipMalloc (synchronises when it grows)
 

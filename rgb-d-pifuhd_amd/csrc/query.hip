@@ -1326,25 +1326,6 @@ struct ColTables {
     int64_t col_base = 0, ncols = 0, ncols_pad = 0;
 };
 
-static int prof_begin(pifu_ctx *ctx, hipStream_t st, hipEvent_t *e1)
-{
-    *e1 = nullptr;
-    if (!ctx->prof_on) return PIFU_OK;
-    if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-        hipEvent_t a0, a1;
-        // device-scope release only: a system-scope fence per event costs ~5 us of idle GPU around every timed launch
-        PIFU_HIP(hipEventCreateWithFlags(&a0, hipEventDisableSystemFence));
-        PIFU_HIP(hipEventCreateWithFlags(&a1, hipEventDisableSystemFence));
-        ctx->prof_ev.push_back(a0);
-        ctx->prof_ev.push_back(a1);
-    }
-    hipEvent_t e0 = ctx->prof_ev[ctx->prof_used];
-    *e1 = ctx->prof_ev[ctx->prof_used + 1];
-    ctx->prof_used += 2;
-    PIFU_HIP(hipEventRecord(e0, st));
-    return PIFU_OK;
-}
-
 // hi / lo planes (bf16, or fp16 scaled by 2^11) of a packed fp32 weight matrix, built on the device the first time the
 // matrix is used in the current precision mode (pifu_set_precision drops the planes of the other mode)
 static int split_planes(pifu_ctx *ctx, const float *W, size_t n, const __bf16 **hi, const __bf16 **lo, hipStream_t st)
@@ -1400,23 +1381,17 @@ static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
         int rc = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
         if (rc) return rc;
         hipEvent_t e1b;
-        rc = prof_begin(ctx, st, &e1b);
+        rc = pifu_prof_begin(ctx, PIFU_PROF_GEMM, st, &e1b);
         if (rc) return rc;
         if (ctx->precision == 2) hipLaunchKernelGGL(k_mlp_gemm_split<1>, dim3(nblocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_mlp_gemm_split<0>, dim3(nblocks), dim3(256), 0, st, a);
-        if (e1b) { PIFU_HIP(hipEventRecord(e1b, st)); ctx->prof_flops += flops; ctx->prof_launches += 1; }
-        return PIFU_OK;
+        return pifu_prof_end(ctx, PIFU_PROF_GEMM, e1b, flops, st);
     }
     hipEvent_t e1;
-    int rc = prof_begin(ctx, st, &e1);
+    int rc = pifu_prof_begin(ctx, PIFU_PROF_GEMM, st, &e1);
     if (rc) return rc;
     launch_fp32_gemm(ctx, a, st);
-    if (e1) {
-        PIFU_HIP(hipEventRecord(e1, st));
-        ctx->prof_flops += flops;
-        ctx->prof_launches += 1;
-    }
-    return PIFU_OK;
+    return pifu_prof_end(ctx, PIFU_PROF_GEMM, e1, flops, st);
 }
 
 // per-column sampled features and products for columns [col_base, col_base + ncols)
@@ -1727,7 +1702,17 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             continue;
         }
         // the chunk geometry indexes points relative to the batch start: src.first already points there
-        hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
+        {
+            hipEvent_t es;
+            rc = pifu_prof_begin(ctx, PIFU_PROF_SAMPLER, st, &es);
+            if (rc != PIFU_OK) return rc;
+            hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
+            // algorithmic bytes of the per-point sampler: 4 bilinear taps x (coarse + fine channels) gathered, one MLP
+            // input row (coarse + fine) written, per valid point
+            const double per_point = 4.0 * (sa.Ccp + (fine ? sa.Cfp : 0)) * 4.0 + (double)(pl.ldc + pl.ldf) * 4.0;
+            rc = pifu_prof_end(ctx, PIFU_PROF_SAMPLER, es, per_point * (double)npts, st);
+            if (rc != PIFU_OK) return rc;
+        }
         rc = launch_level(ctx, 0, pl, g, rows, pl.mask, 1, coarse_dst, upto, st);
         if (rc != PIFU_OK) return rc;
         if (phi && total_chunks == 1) {
@@ -1823,32 +1808,5 @@ extern "C" int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream str
     PIFU_HIP(hipGetLastError());
     PIFU_HIP(hipMemcpyAsync(out, ctx->clock_buf, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PIFU_HIP(hipStreamSynchronize(st));
-    return PIFU_OK;
-}
-
-extern "C" int pifu_profile_enable(pifu_ctx *ctx, int on)
-{
-    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_profile_enable: null context");
-    ctx->prof_on = on != 0;
-    return PIFU_OK;
-}
-
-extern "C" int pifu_profile_read(pifu_ctx *ctx, double *gemm_ms, int64_t *gemm_launches, double *gemm_flops, int reset)
-{
-    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_profile_read: null context");
-    PIFU_HIP(hipSetDevice(ctx->device));
-    PIFU_HIP(hipDeviceSynchronize());
-    double ms = ctx->prof_ms_acc;
-    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
-        float t = 0.f;
-        PIFU_HIP(hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
-        ms += t;
-    }
-    ctx->prof_ms_acc = ms;
-    ctx->prof_used = 0;                      // events can be recycled: their time is folded into the accumulator
-    if (gemm_ms) *gemm_ms = ms;
-    if (gemm_launches) *gemm_launches = ctx->prof_launches;
-    if (gemm_flops) *gemm_flops = ctx->prof_flops;
-    if (reset) { ctx->prof_ms_acc = 0.0; ctx->prof_flops = 0.0; ctx->prof_launches = 0; }
     return PIFU_OK;
 }

@@ -17,11 +17,25 @@ import numpy as np
 import torch
 
 
+# Self-test switch: with a process group of ONE rank the sharded entry points normally skip their collectives; setting
+# this makes them run the full multi-rank code path (padding, all-gather, re-assembly) anyway.  It exists so that the RCCL
+# transport can be exercised end to end on a single-GPU box (tests/test_gpu_dist.py, bench.py --dist-selftest).
+ALWAYS_COLLECTIVE = False
+
+
 def world():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def collective_active():
+    """True when the sharded entry points exchange data: more than one rank, or the single-rank self-test."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or ALWAYS_COLLECTIVE
 
 
 def shard_chunks(total_points: int, chunk: int, world_size: int, rank: int):
@@ -44,7 +58,7 @@ def sharded_eval(total_points: int, chunk: int, eval_fn, device, group=None):
     identical on every rank."""
     import torch.distributed as dist
     rank, ws = world()
-    if ws == 1:
+    if not collective_active():
         return eval_fn(0, total_points)
     first, count, per = shard_chunks(total_points, chunk, ws, rank)
     slot = per * chunk
@@ -136,7 +150,7 @@ def sharded_calls(spans, call_fn, width, device, group=None):
     rank, ws = world()
     n_rows = spans[-1][1] if spans else 0
     out = torch.zeros(n_rows, width, device=device, dtype=torch.float32)
-    if ws == 1:
+    if not collective_active():
         for (l, r) in spans:
             out[l:r] = call_fn(l, r)
         return out

@@ -102,7 +102,7 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     (`pifuhd_amd.dist`); every rank gets the identical field and runs marching cubes redundantly."""
     ctx = _ctx_of(net)
     from . import dist as pdist
-    if sharded and pdist.world()[1] > 1:
+    if sharded and pdist.collective_active():
         flags = _lib.Q_COARSE_ONLY if isinstance(net, PIFuNetwNML) else 0
         R = int(resolution)
         if use_octree:

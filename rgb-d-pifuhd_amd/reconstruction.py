@@ -81,6 +81,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     from . import dist as pdist
     dev = net.device
     rank, ws = pdist.world() if sharded else (0, 1)
+    exchange = sharded and pdist.collective_active()
 
     def mark():
         if timings is not None:
@@ -111,7 +112,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=50000)
         return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
 
-    if ws > 1:
+    if exchange:
         i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
         mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
         runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in

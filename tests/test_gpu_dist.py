@@ -73,3 +73,69 @@ def test_gen_mesh_sharded_world2_matches_single_process(tmp_path):
     # rank 0 writes the files, the other ranks do not
     assert open(tmp_path / 'mesh_r0.obj').read() == open(path).read()
     assert not os.path.exists(tmp_path / 'mesh_r1.obj')
+
+
+def _rccl_worker(port, outdir):
+    """One rank, backend nccl (= RCCL): the sharded entry points with their collectives forced on must reproduce the
+    plain single-process results bit for bit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import dist as pdist, reconstruction
+    netMR, data = _build()
+    want_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
+    want_oct, n_want = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
+    want = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'plain.obj'))
+    pdist.ALWAYS_COLLECTIVE = True
+    assert pdist.collective_active()
+    got_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
+    got_oct, n_got = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
+    got = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl.obj'), sharded=True)
+    t = torch.tensor([3.0], device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    ok = (torch.equal(want_field, got_field) and torch.equal(want_oct, got_oct) and n_want == n_got
+          and all(np.array_equal(a, b) for a, b in zip(want, got)) and float(t.item()) == 3.0
+          and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'rccl.obj')).read())
+    with open(os.path.join(outdir, 'rccl_ok.txt'), 'w') as f:
+        f.write('%s %s' % (ok, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_transport_single_rank(tmp_path):
+    """The `nccl` (RCCL) branch of the sharded path, on the one GPU this box has: process group of one rank, every
+    collective of the path executed (all_gather_into_tensor of the field and of the colours, all_reduce, barrier), results
+    identical to the collective-free run.  No scaling claim - only that the transport initialises, runs and shuts down."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    p = ctx.Process(target=_rccl_worker, args=(port, str(tmp_path)))
+    p.start()
+    p.join(timeout=800)
+    assert p.exitcode == 0
+    assert open(tmp_path / 'rccl_ok.txt').read() == 'True nccl'
+
+
+@pytest.mark.timeout(900)
+def test_bench_dist_selftest_under_torchrun(tmp_path):
+    """bench.py exactly as the driver launches it for N GPUs (python -m torch.distributed.run ... bench.py --gpus N), with
+    N = 1 and --dist-selftest so that the process group (backend nccl) is created and the N > 1 code path runs."""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), 'bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--res', '64',
+           '--genmesh-res', '64', '--batch-rows', '262144', '--dist-selftest', '--no-cpu-baseline', '--no-split-precision',
+           '--no-lean-pass', '--no-canonical']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['dist_selftest']['backend'] == 'nccl' and line['n_gpus'] == 1 and line['value'] > 0
+    assert 'error' not in line['gen_mesh'].get('one_subject_sharded', {'error': 1})
