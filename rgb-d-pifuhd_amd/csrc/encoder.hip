@@ -4,16 +4,18 @@
 //
 // Layout: every activation is NHWC fp32 ([pixel][channel], channel stride `ld` so that a tensor can be a
 // channel slice of a wider buffer: the ConvBlock concat is written in place).  A convolution is an
-// implicit GEMM: rows = output pixels, K = taps x input channels (channels padded to the 32-wide K step),
-// columns = output channels; the A tile is gathered tap by tap while it is staged into LDS, with the
-// preceding norm (+ReLU) fused into that staging pass as a per-channel scale/shift (the pre-activation
-// ConvBlock is conv(relu(norm(x)))), zero / reflection padding applied AFTER the activation.  Same exact-
-// fp32 MFMA core (v_mfma_f32_32x32x2_f32, 128x128x32 tile, 4 waves x 64x64) as the MLP GEMM.  Statistics
+// implicit GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): rows = output pixels, columns = output channels,
+// K = kernel rows x (kernel columns x input channels).  The preceding norm (+ReLU) of the pre-activation ConvBlock
+// (conv(relu(norm(x)))) is applied ONCE per input element by k_prep_act, which also materialises the zero / mirrored
+// border (padding comes AFTER the activation); the GEMM kernel k_conv_dma then moves both operand tiles global -> LDS
+// by LDS-DMA with no per-tap address or transform arithmetic left (see the section comment below).  Statistics
 // for train-mode BatchNorm / InstanceNorm / GroupNorm come from a separate per-channel reduction pass
 // (deterministic, double accumulation across blocks).
 #include "pifu_internal.h"
 
 #include <math.h>
+
+#include <algorithm>
 
 #include <map>
 #include <string>
@@ -23,197 +25,295 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LD = BK + 4;
-constexpr int TILE = BM * LD;
+constexpr int BM = 128, BK = 32;      // GEMM rows per block, K step (the N tile is a template parameter: 64 or 32)
 
-struct ConvArgs {
-    const float *X;         // input NHWC
-    int Hin, Win, ldx;
-    int cin;                // channels per tap, multiple of 32 (input buffers are padded accordingly)
-    const float *scale;     // per-channel prologue (ones / zeros / slope 1 for a raw input)
+// ======================================================================================================
+// Convolution as an implicit GEMM whose BOTH operands reach LDS by LDS-DMA (k_conv_dma).
+//
+// What made k_conv_gemm slow (56 TFLOP/s on a 128 -> 128 3x3 layer with no padding waste at all) is its staging pass: per
+// K step and thread ~200 vector instructions of tap addressing, bounds / reflection logic and the norm + ReLU transform,
+// on a chip whose fp32 MFMA shares the vector ALU.  Here that work is done ONCE per input element instead of once per tap
+// and output-channel tile: k_prep_act writes act(norm(x)) into a border-padded copy P (zeros or mirrored pixels), after
+// which every A row of the implicit GEMM is a plain contiguous run of floats - for one kernel row dy the taps dx = 0..k-1
+// of a pixel are k * C consecutive floats of P - and a K step is `base(row) + scalar offset`.  Both tiles then move by
+// `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write, no transform), double-buffered with ONE barrier per K step.
+// K order: kernel row dy, then the k * C floats of that row (dx-major, channel-minor), each row padded to the 32-float
+// K step with zero WEIGHTS (the A side then reads the following pixels, which are finite).  7x7 convs on few channels pack
+// densely this way (7 x 84 -> 7 x 96 for 12 channels instead of 49 x 32).  N tile = 64 or 32 output channels (three or four blocks per CU), so
+// that the 32 / 64-channel layers of the hourglass ConvBlocks issue no padding MFMAs.
+// LDS image of both tiles: unpadded [rows][32 floats] with the eight 16-byte chunks of a row XOR-swizzled by
+// (row >> 1) & 7 - applied to the SOURCE address of the DMA (the LDS side of an LDS-DMA is lane-linear) and to the fragment
+// read - which makes every ds_read_b128 of the MFMA operand fragments bank-conflict free.
+// ======================================================================================================
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// One LDS-DMA piece (1 KB per wave): lane i's 16 bytes land at lds_addr + 16 i.  Issued from asm so that the compiler
+// does not order it in front of every later ds_read with a full vmcnt(0); the kernel waits for its DMAs itself.  `s_nop 4`:
+// SGPR operands may come fresh from a VALU readfirstlane; `s_nop 0`: M0 write -> LDS-DMA.  M0 is saved and restored.
+__device__ __forceinline__ void lds_dma1(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff)
+{
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+struct PrepArgs {
+    const float *X;         // source NHWC [H][W], channel stride ldx (>= Cp readable channels per pixel)
+    int H, W, ldx;
+    const float *scale;     // per-channel norm affine of the consumer's prologue (>= Cp entries)
     const float *shift;
-    float slope;            // 0 = ReLU, 1 = identity
-    int RW;                 // logical row grid width (rows = RH * RW)
-    int nrows;
-    int os, oy0, ox0;       // output pixel = (ry * os + oy0, rx * os + ox0)
-    int Wout;
-    int is;                 // input step: input pixel of tap t = (ry * is + dy_t, rx * is + dx_t)
-    int ntaps;
-    const short2 *taps;     // (dy, dx) per tap, device
-    int reflect;            // 1 = reflection padding, 0 = zeros
-    const float *W;         // [cout_pad][ntaps * cin]
-    const float *bias;      // [cout_pad] (zeros if the conv has no bias)
-    float *Y;               // output NHWC (already offset to the first output channel of this conv)
-    int ldy;
-    const float *R;         // optional residual added in the epilogue (same pixel indexing as Y)
-    int ldr;
-    int cout;               // valid output channels
-    int ntm, ntn;
-    // split-K (launches with too few tiles to fill the chip): split s accumulates K steps [s * steps_per_split, ...) into
-    // part[s][row][col] (raw, no bias); k_conv_splitk_reduce sums the splits in order and applies the epilogue
-    int nsplit, steps_per_split, tiles_per_split;
-    float *part;            // [nsplit][ntm * BM][ntn * BN]
+    float slope;            // act(t) = max(t, slope * t): 0 ReLU, 1 identity
+    int pad_lo, reflect;    // border in front of row / column 0; reflect: mirrored pixels instead of zeros
+    float *P;               // destination [Hp][Wp][Cp] + 64 zero floats of slack
+    int Hp, Wp, Cp;         // Cp % 4 == 0
 };
 
-__global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvArgs a)
+__global__ void k_prep_act(const PrepArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+    const int cg = a.Cp / 4;
+    const size_t total = (size_t)a.Hp * a.Wp * cg;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) {
+        if (i < total + 16) *reinterpret_cast<float4 *>(a.P + (size_t)a.Hp * a.Wp * a.Cp + (i - total) * 4) = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const int c = (int)(i % cg) * 4;
+    const size_t p = i / cg;
+    int iy = (int)(p / a.Wp) - a.pad_lo, ix = (int)(p % a.Wp) - a.pad_lo;
+    bool inside = true;
+    if (a.reflect) {
+        iy = iy < 0 ? -iy : (iy >= a.H ? 2 * (a.H - 1) - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= a.W ? 2 * (a.W - 1) - ix : ix);
+    } else {
+        inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    }
+    float4 v = make_float4(0, 0, 0, 0);
+    if (inside) {       // padding is applied AFTER the activation: border pixels are exact zeros
+        v = *reinterpret_cast<const float4 *>(a.X + ((size_t)iy * a.W + ix) * a.ldx + c);
+        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c), sh = *reinterpret_cast<const float4 *>(a.shift + c);
+        float t;
+        t = fmaf(v.x, sc.x, sh.x); v.x = fmaxf(t, a.slope * t);
+        t = fmaf(v.y, sc.y, sh.y); v.y = fmaxf(t, a.slope * t);
+        t = fmaf(v.z, sc.z, sh.z); v.z = fmaxf(t, a.slope * t);
+        t = fmaf(v.w, sc.w, sh.w); v.w = fmaxf(t, a.slope * t);
+    }
+    *reinterpret_cast<float4 *>(a.P + p * a.Cp + c) = v;
+}
+
+constexpr int CONV_MAX_SPANS = 8;
+
+struct ConvDmaArgs {
+    const float *P;             // padded activated input
+    unsigned p_bytes;           // bytes of P incl. slack (buffer bound of the descriptor)
+    int Wp, C;                  // padded width, channels per pixel
+    int RW, nrows, is;          // logical output grid width, number of output rows, input step
+    int nspan;                  // contiguous K runs ("kernel rows")
+    int span_off[CONV_MAX_SPANS];     // byte offset of a run's first float relative to the row's base pixel
+    int span_steps[CONV_MAX_SPANS];   // 32-float K steps of the run
+    const float *W;             // [cout_pad][ldw], K order as above
+    int ldw;                    // 32 * total K steps
+    const float *bias;          // [cout_pad]
+    float *Y; int ldy;
+    const float *R; int ldr;    // optional residual
+    int cout;
+    int os, oy0, ox0, Wout;     // output pixel = (ry * os + oy0, rx * os + ox0)
+    int ntm, ntn;
+    // split-K (launches with too few tiles to fill the chip): split s accumulates K steps [s * steps_per_split, ...) into
+    // part[s][row][col] (raw, no bias); k_conv_dma_reduce sums the splits in a fixed order and applies the epilogue
+    int nsplit, steps_per_split, tiles_per_split;
+    float *part;                // [nsplit][ntm * BM][ntn * TN]
+    int ldp;                    // ntn * TN
+    // fused statistics of the values this launch stores (unsplit launches): per (128-row tile, output channel) sum and
+    // sum of squares, as the [tile][cout][2] double partials k_stats_finalize reduces - the norm that follows the conv
+    // then needs no pass of its own over the tensor
+    double *stat;               // or null
+    int stat_tile0;             // first partial row of this launch (the four parity classes of a transposed conv share one set)
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void k_conv_dma(const ConvDmaArgs a)
+{
+    constexpr int WN = TN == 32 ? 1 : 2, WM = 4 / WN;          // wave grid
+    constexpr int MT = (BM / WM) / 32, NT = (TN / WN) / 32;    // 32 x 32 accumulators per wave
+    constexpr int ATILE = BM * BK, WTILE = TN * BK, NS = BK / 8;
+    constexpr int WPIECES = TN / 32;                           // LDS-DMA pieces of the W tile per wave
+    __shared__ __attribute__((aligned(16))) float lds[2 * ATILE + 2 * WTILE];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int split = blockIdx.x / a.tiles_per_split, bt = blockIdx.x - split * a.tiles_per_split;
     const int xcd = bt & 7, slot = bt >> 3;
     const int tile_n = slot % a.ntn;
     const int tile_m = (slot / a.ntn) * 8 + xcd;
     if (tile_m >= a.ntm) return;
-    const int row0 = tile_m * BM, col0 = tile_n * BN;
-    const int kq = tid & 7, sr = tid >> 3;
-    const int ldw = a.ntaps * a.cin;
+    const int row0 = tile_m * BM, col0 = tile_n * TN;
     const int step_lo = split * a.steps_per_split;
-    const int step_hi = min(ldw / BK, step_lo + a.steps_per_split);
+    const int step_hi = min(a.ldw / BK, step_lo + a.steps_per_split);
 
-    // the 4 rows this thread stages: logical (ry, rx) -> input base pixel
-    int by0, bx0, by1, bx1, by2, bx2, by3, bx3;
-    bool v0, v1, v2, v3;
-    {
-        int r;
-        r = row0 + sr;      v0 = r < a.nrows; by0 = (r / a.RW) * a.is; bx0 = (r % a.RW) * a.is;
-        r = row0 + sr + 32; v1 = r < a.nrows; by1 = (r / a.RW) * a.is; bx1 = (r % a.RW) * a.is;
-        r = row0 + sr + 64; v2 = r < a.nrows; by2 = (r / a.RW) * a.is; bx2 = (r % a.RW) * a.is;
-        r = row0 + sr + 96; v3 = r < a.nrows; by3 = (r / a.RW) * a.is; bx3 = (r % a.RW) * a.is;
+    const unsigned long long pa = (unsigned long long)a.P, wa = (unsigned long long)(a.W + (size_t)col0 * a.ldw);
+    const u32x4 rP = {(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, a.p_bytes, 0x00020000u};
+    const u32x4 rWt = {(unsigned)wa, (unsigned)(wa >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+    // DMA lane mapping: lane (r8 = lane >> 3, p = lane & 7) of wave w fills, in pass q, chunk position p of tile row
+    // 32 q + 8 w + r8 with the logical chunk p ^ f(row), f(row) = (row >> 1) & 7 (independent of q)
+    const int trow = wave * 8 + (lane >> 3);
+    const unsigned chunk = (unsigned)(((lane & 7) ^ ((trow >> 1) & 7)) << 4);
+    unsigned voA[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int r = row0 + trow + 32 * q;
+        r = r < a.nrows ? r : a.nrows - 1;                     // tile tail: any valid row (its outputs are never stored)
+        const int ry = r / a.RW, rx = r - ry * a.RW;
+        voA[q] = (unsigned)((ry * a.is) * a.Wp + rx * a.is) * (unsigned)a.C * 4u + chunk;
     }
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rsc, rsh;
-    bool m0, m1, m2, m3;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const unsigned voW = (unsigned)trow * ldw4 + chunk;
+    const unsigned a_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)(lds + wave * 8 * BK));
+    const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)(lds + 2 * ATILE + wave * 8 * BK));
 
-#define CONV_SRC(by_, bx_, vrow_, dst_, msk_)                                                          \
+    // K cursor of the next step to fetch, positioned on this split's first step
+    int c_span = 0, c_left = step_lo;
+    while (c_left >= a.span_steps[c_span]) { c_left -= a.span_steps[c_span]; ++c_span; }
+    unsigned c_soff = (unsigned)a.span_off[c_span] + (unsigned)c_left * (BK * 4u), c_kw4 = (unsigned)step_lo * (BK * 4u);
+    c_left = a.span_steps[c_span] - c_left;
+#define CONV_FETCH(buf_)                                                                               \
     {                                                                                                  \
-        int iy = (by_) + tp.x, ix = (bx_) + tp.y;                                                      \
-        if (a.reflect) {                                                                               \
-            iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * (a.Hin - 1) - iy : iy);                             \
-            ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * (a.Win - 1) - ix : ix);                             \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+            lds_dma1(a_lds + (unsigned)(buf_) * (ATILE * 4u) + q * 4096u, voA[q], rP, c_soff);         \
+        _Pragma("unroll") for (int q = 0; q < WPIECES; ++q)                                            \
+            lds_dma1(w_lds + (unsigned)(buf_) * (WTILE * 4u) + q * 4096u, voW, rWt, c_kw4 + q * 32u * ldw4); \
+        c_soff += BK * 4u;                                                                             \
+        c_kw4 += BK * 4u;                                                                              \
+        if (--c_left == 0 && ++c_span < a.nspan) {                                                     \
+            c_left = a.span_steps[c_span];                                                             \
+            c_soff = (unsigned)a.span_off[c_span];                                                     \
         }                                                                                              \
-        msk_ = (vrow_) && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;                              \
-        dst_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
-        if (msk_) dst_ = *reinterpret_cast<const float4 *>(a.X + ((size_t)iy * a.Win + ix) * a.ldx + cc); \
-    }
-#define CONV_GLOAD(step_)                                                                              \
-    {                                                                                                  \
-        const int kk = (step_) * BK;                                                                   \
-        const int t = kk / a.cin;                                                                      \
-        const int cc = kk - t * a.cin + kq * 4;                                                        \
-        const short2 tp = a.taps[t];                                                                   \
-        CONV_SRC(by0, bx0, v0, ra0, m0) CONV_SRC(by1, bx1, v1, ra1, m1)                                \
-        CONV_SRC(by2, bx2, v2, ra2, m2) CONV_SRC(by3, bx3, v3, ra3, m3)                                \
-        rsc = *reinterpret_cast<const float4 *>(a.scale + cc);                                         \
-        rsh = *reinterpret_cast<const float4 *>(a.shift + cc);                                         \
-        const float *wp = a.W + (size_t)(col0 + sr) * ldw + kk + kq * 4;                               \
-        rw0 = *reinterpret_cast<const float4 *>(wp);                                                   \
-        rw1 = *reinterpret_cast<const float4 *>(wp + (size_t)32 * ldw);                                \
-        rw2 = *reinterpret_cast<const float4 *>(wp + (size_t)64 * ldw);                                \
-        rw3 = *reinterpret_cast<const float4 *>(wp + (size_t)96 * ldw);                                \
-    }
-#define CONV_XF(v_, m_)                                                                                \
-    {                                                                                                  \
-        float t_;                                                                                      \
-        t_ = fmaf(v_.x, rsc.x, rsh.x); v_.x = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
-        t_ = fmaf(v_.y, rsc.y, rsh.y); v_.y = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
-        t_ = fmaf(v_.z, rsc.z, rsh.z); v_.z = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
-        t_ = fmaf(v_.w, rsc.w, rsh.w); v_.w = (m_) ? fmaxf(t_, a.slope * t_) : 0.f;                    \
-    }
-#define CONV_LSTORE(buf_)                                                                              \
-    {                                                                                                  \
-        float *la = lds + (buf_) * 2 * TILE + sr * LD + kq * 4;                                        \
-        float *lb = la + TILE;                                                                         \
-        CONV_XF(ra0, m0) CONV_XF(ra1, m1) CONV_XF(ra2, m2) CONV_XF(ra3, m3)                            \
-        *reinterpret_cast<float4 *>(la) = ra0;                                                         \
-        *reinterpret_cast<float4 *>(la + 32 * LD) = ra1;                                               \
-        *reinterpret_cast<float4 *>(la + 64 * LD) = ra2;                                               \
-        *reinterpret_cast<float4 *>(la + 96 * LD) = ra3;                                               \
-        *reinterpret_cast<float4 *>(lb) = rw0;                                                         \
-        *reinterpret_cast<float4 *>(lb + 32 * LD) = rw1;                                               \
-        *reinterpret_cast<float4 *>(lb + 64 * LD) = rw2;                                               \
-        *reinterpret_cast<float4 *>(lb + 96 * LD) = rw3;                                               \
-    }
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    CONV_GLOAD(step_lo)
-    CONV_LSTORE(0)
-    __syncthreads();
-    for (int step = step_lo; step < step_hi; ++step) {
-        const int buf = (step - step_lo) & 1;
-        const bool more = step + 1 < step_hi;
-        if (more) CONV_GLOAD(step + 1)
-        const float *A = lds + buf * 2 * TILE + (wm * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        const float *B = lds + buf * 2 * TILE + TILE + (wn * 64 + (lane & 31)) * LD + (lane >> 5) * 4;
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(A + s * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(A + 32 * LD + s * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(B + s * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(B + 32 * LD + s * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0[t], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv1[t], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv0[t], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv1[t], acc11, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) CONV_LSTORE(buf ^ 1)
-        __syncthreads();
     }
 
     const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    CONV_FETCH(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the DMAs of the first step have landed
+    __syncthreads();
+
+    const char *Al = reinterpret_cast<const char *>(lds) + (wm * (BM / WM) + j) * (BK * 4);
+    const char *Bl = reinterpret_cast<const char *>(lds + 2 * ATILE) + (wn * (TN / WN) + j) * (BK * 4);
+    const unsigned hf = (unsigned)((h ^ ((j >> 1) & 7)) << 4);
+    for (int step = step_lo; step < step_hi; ++step) {
+        const int buf = (step - step_lo) & 1;
+        if (step + 1 < step_hi) CONV_FETCH(buf ^ 1)
+        const char *A = Al + buf * (ATILE * 4), *B = Bl + buf * (WTILE * 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned off = hf ^ (unsigned)(s * 32);
+            float4 af[MT], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4 *>(A + mt * 32 * BK * 4 + off);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const float4 *>(B + nt * 32 * BK * 4 + off);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float av = t == 0 ? af[mt].x : (t == 1 ? af[mt].y : (t == 2 ? af[mt].z : af[mt].w));
+                        const float bv = t == 0 ? bf[nt].x : (t == 1 ? bf[nt].y : (t == 2 ? bf[nt].z : bf[nt].w));
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][nt], 0, 0, 0);
+                    }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the tiles of step + 1 have landed
+        __syncthreads();                         // ... and every wave is done with the tiles of this step
+    }
+#undef CONV_FETCH
+
     if (a.nsplit > 1) {     // raw partial tile; rows / columns beyond the valid range are written too (never read)
-        float *P = a.part + ((size_t)split * a.ntm * BM + row0) * ((size_t)a.ntn * BN) + col0;
+        float *Pt = a.part + ((size_t)split * a.ntm * BM + row0) * (size_t)a.ldp + col0;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    P[(size_t)(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ((size_t)a.ntn * BN) + wn * 64 + nt * 32 + j] = acc[r];
-            }
+                    Pt[(size_t)(wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * (size_t)a.ldp + wn * (TN / WN) + nt * 32 + j] =
+                        acc[mt][nt][r];
         return;
     }
+    const bool plain = a.os == 1 && a.RW == a.Wout && a.oy0 == 0 && a.ox0 == 0;
+    float ssum[NT], ssq[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = col0 + wn * 64 + nt * 32 + j;
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.f; ssq[nt] = 0.f;
+        const int col = col0 + wn * (TN / WN) + nt * 32 + j;
         const bool cok = col < a.cout;
         const float bias = cok ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f32x16 &acc = nt == 0 ? (mt == 0 ? acc00 : acc10) : (mt == 0 ? acc01 : acc11);
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = row0 + wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (cok && row < a.nrows) {
-                    const int ry = row / a.RW, rx = row - ry * a.RW;
-                    const size_t pix = (size_t)(ry * a.os + a.oy0) * a.Wout + (rx * a.os + a.ox0);
-                    float v = acc[r] + bias;
+                    size_t pix = (size_t)row;            // plain convolution: output pixel = GEMM row
+                    if (!plain) {
+                        const int ry = row / a.RW, rx = row - ry * a.RW;
+                        pix = (size_t)(ry * a.os + a.oy0) * a.Wout + (rx * a.os + a.ox0);
+                    }
+                    float v = acc[mt][nt][r] + bias;
                     if (a.R) v += a.R[pix * a.ldr + col];
                     a.Y[pix * a.ldy + col] = v;
+                    ssum[nt] += v;
+                    ssq[nt] = fmaf(v, v, ssq[nt]);
                 }
             }
         }
     }
+    if (a.stat) {       // (the operand tiles are dead: every wave passed the loop's final barrier)
+        float *red = lds;                                    // [2 (sum | squares)][WM][TN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float sv = ssum[nt] + __shfl_xor(ssum[nt], 32), qv = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (lane < 32) {
+                red[(0 * WM + wm) * TN + wn * (TN / WN) + nt * 32 + j] = sv;
+                red[(1 * WM + wm) * TN + wn * (TN / WN) + nt * 32 + j] = qv;
+            }
+        }
+        __syncthreads();
+        if (tid < TN && col0 + tid < a.cout) {
+            double sd = 0.0, qd = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { sd += (double)red[(0 * WM + w) * TN + tid]; qd += (double)red[(1 * WM + w) * TN + tid]; }
+            double *dst = a.stat + ((size_t)(a.stat_tile0 + tile_m) * a.cout + col0 + tid) * 2;
+            dst[0] = sd;
+            dst[1] = qd;
+        }
+    }
 }
 
-// split-K epilogue: Y = sum_s part[s] (fixed order) + bias (+ residual), with the conv's output pixel mapping
-__global__ void k_conv_splitk_reduce(const ConvArgs a)
+// split-K epilogue of k_conv_dma: Y = sum_s part[s] (fixed order) + bias (+ residual), with the conv's output pixel mapping
+__global__ void k_conv_dma_reduce(const ConvDmaArgs a)
 {
-    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) % (a.ntn * BN / 4);
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) / (a.ntn * BN / 4);
+    const int ldp4 = a.ldp / 4;
+    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) % ldp4;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) / ldp4;
     if (row >= a.nrows || c4 * 4 >= a.cout) return;
-    const size_t ldp = (size_t)a.ntn * BN, plane = (size_t)a.ntm * BM * ldp;
-    float4 v = *reinterpret_cast<const float4 *>(a.part + (size_t)row * ldp + c4 * 4);
+    const size_t plane = (size_t)a.ntm * BM * a.ldp;
+    float4 v = *reinterpret_cast<const float4 *>(a.part + (size_t)row * a.ldp + c4 * 4);
     for (int s = 1; s < a.nsplit; ++s) {
-        const float4 p = *reinterpret_cast<const float4 *>(a.part + s * plane + (size_t)row * ldp + c4 * 4);
+        const float4 p = *reinterpret_cast<const float4 *>(a.part + s * plane + (size_t)row * a.ldp + c4 * 4);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
     const int ry = row / a.RW, rx = row - ry * a.RW;
@@ -250,6 +350,44 @@ __global__ void k_channel_stats(const float *X, int ld, int C, int P, int rows_p
         }
     }
     // reduce over tr in a fixed order through LDS, one channel component at a time
+    for (int k = 0; k < 4; ++k) {
+        __syncthreads();
+        sh[threadIdx.x * 2] = s[k];
+        sh[threadIdx.x * 2 + 1] = q[k];
+        __syncthreads();
+        if (tr == 0 && c4 < cg) {
+            double ds = 0, dq = 0;
+            for (int t = 0; t < tpr; ++t) { ds += sh[(t * cg + c4) * 2]; dq += sh[(t * cg + c4) * 2 + 1]; }
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2] = ds;
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2 + 1] = dq;
+        }
+    }
+}
+
+// out = a + b (the identity shortcut of a ConvBlock) with the statistics of `out` in the same pass: same block geometry and
+// partial layout as k_channel_stats
+__global__ void k_add_stats(const float *A, int lda, const float *B, int ldb, float *O, int ldo, int C, int P, int rows_per_block,
+                            double *partial /* [nb][C][2] */)
+{
+    __shared__ double sh[256 * 2];
+    const int cg = C / 4;
+    const int tpr = blockDim.x / cg > 0 ? blockDim.x / cg : 1;
+    const int c4 = threadIdx.x % cg, tr = threadIdx.x / cg;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(P, r0 + rows_per_block);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < tpr && c4 < cg) {
+        for (int r = r0 + tr; r < r1; r += tpr) {
+            const float4 x = *reinterpret_cast<const float4 *>(A + (size_t)r * lda + c4 * 4);
+            const float4 y = *reinterpret_cast<const float4 *>(B + (size_t)r * ldb + c4 * 4);
+            const float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+            *reinterpret_cast<float4 *>(O + (size_t)r * ldo + c4 * 4) = v;
+            s[0] += v.x; q[0] = fmaf(v.x, v.x, q[0]);
+            s[1] += v.y; q[1] = fmaf(v.y, v.y, q[1]);
+            s[2] += v.z; q[2] = fmaf(v.z, v.z, q[2]);
+            s[3] += v.w; q[3] = fmaf(v.w, v.w, q[3]);
+        }
+    }
     for (int k = 0; k < 4; ++k) {
         __syncthreads();
         sh[threadIdx.x * 2] = s[k];
@@ -508,6 +646,10 @@ __global__ void k_nhwc_to_nchw(const float *src, int ld, int C, int HW, float *d
 struct Tensor {
     float *p = nullptr;
     int H = 0, W = 0, C = 0, ld = 0;
+    // (sum, sum^2) partials [stat_nb][C][2] of exactly these C channels in their CURRENT values, when the producing kernel
+    // left them behind (conv epilogue, k_add_stats) or a norm already reduced them; null: the norm makes its own pass
+    double *stat = nullptr;
+    int stat_nb = 0;
     size_t pixels() const { return (size_t)H * W; }
 };
 
@@ -526,9 +668,11 @@ struct EncState {
     std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
     DevBuf arena;
     DevBuf splitk;                               // partial tiles of split-K convolutions (reused, stream-ordered)
+    DevBuf prep;                                 // activated + padded input of the convolution in flight (k_prep_act)
     size_t used = 0;
     hipStream_t st = nullptr;
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
+    bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
     std::string err;
 };
 
@@ -567,6 +711,8 @@ Tensor slice(const Tensor &t, int c0, int c)
     Tensor s = t;
     s.p = t.p + c0;
     s.C = c;
+    s.stat = nullptr;
+    s.stat_nb = 0;
     return s;
 }
 
@@ -594,8 +740,21 @@ Affine raw(EncState &S) { return Affine{ones(S), zeros(S), 1.f}; }
 
 inline unsigned nblk(size_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+int stat_rows_per_block(int P)
+{
+    int rows = (P + 255) / 256;
+    return rows < 8 ? 8 : (rows > 1024 ? 1024 : rows);
+}
+
+int stat_threads(int C)
+{
+    const int cg = C / 4;
+    if (cg > 1024) throw Fail{"channel count too large for k_channel_stats"};
+    return cg <= 256 ? 256 : (cg <= 512 ? 512 : 1024);
+}
+
 // ---- normalisation: returns the per-channel affine that realises `norm(x)`; slope is set by the caller ----
-Affine norm_affine(EncState &S, const std::string &prefix, const Tensor &x, int norm)
+Affine norm_affine(EncState &S, const std::string &prefix, Tensor &x, int norm)
 {
     Affine a;
     if (norm == 0) {   // BatchNorm2d eval: running statistics, folded once
@@ -621,17 +780,17 @@ Affine norm_affine(EncState &S, const std::string &prefix, const Tensor &x, int 
     const int groups = norm == 2 ? 32 : C;
     const int cpg = C / groups;
     const int P = (int)x.pixels();
-    // ~256 blocks in flight: small maps (32 x 32 x 1024 channels) would otherwise be reduced by a single block
-    int rows_per_block = (P + 255) / 256;
-    if (rows_per_block < 8) rows_per_block = 8;
-    if (rows_per_block > 1024) rows_per_block = 1024;
-    const int nb = (P + rows_per_block - 1) / rows_per_block;
-    double *partial = reinterpret_cast<double *>(arena_take(S, (size_t)nb * C * 2 * 2));
-    const int cg = C / 4;
-    int threads = 256;
-    if (cg > 256) threads = cg <= 512 ? 512 : 1024;
-    if (cg > 1024) throw Fail{"channel count too large for k_channel_stats"};
-    hipLaunchKernelGGL(k_channel_stats, dim3(nb), dim3(threads), 0, S.st, (const float *)x.p, x.ld, C, P, rows_per_block, partial);
+    int nb = x.stat_nb;
+    double *partial = x.stat;
+    if (!partial) {
+        // ~256 blocks in flight: small maps (32 x 32 x 1024 channels) would otherwise be reduced by a single block
+        int rows_per_block = stat_rows_per_block(P);
+        nb = (P + rows_per_block - 1) / rows_per_block;
+        partial = reinterpret_cast<double *>(arena_take(S, (size_t)nb * C * 2 * 2));
+        hipLaunchKernelGGL(k_channel_stats, dim3(nb), dim3(stat_threads(C)), 0, S.st, (const float *)x.p, x.ld, C, P, rows_per_block, partial);
+        x.stat = partial;           // a second norm of the same tensor (ConvBlock bn1 / bn4) reuses the reduction
+        x.stat_nb = nb;
+    }
     float *sc = arena_take(S, C), *sh = arena_take(S, C);
     const float *gamma = nullptr, *beta = nullptr;
     if (norm != 3) {
@@ -651,24 +810,6 @@ struct ConvGeom {
     bool reflect = false;
 };
 
-// weights [Cout][Cin][k][k] -> [cout_pad][taps * cin_pad] (tap-major, then channel)
-const float *packed_conv_weight(EncState &S, const std::string &name, int cin_pad, int cout_pad, int *cout, int *k)
-{
-    const HostParam &w = param(S, name);
-    if (w.shape.size() != 4) throw Fail{name + ": expected a 4-d conv weight"};
-    const int co = (int)w.shape[0], ci = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
-    *cout = co; *k = kh;
-    const std::string key = name + "#pk" + std::to_string(cin_pad) + "_" + std::to_string(cout_pad);
-    if (S.dev.count(key)) return S.dev[key];
-    if (ci > cin_pad) throw Fail{name + ": input channels exceed the padded width"};
-    std::vector<float> pk((size_t)cout_pad * kh * kw * cin_pad, 0.f);
-    for (int o = 0; o < co; ++o)
-        for (int c = 0; c < ci; ++c)
-            for (int t = 0; t < kh * kw; ++t)
-                pk[((size_t)o * kh * kw + t) * cin_pad + c] = w.data[((size_t)o * ci + c) * kh * kw + t];
-    return dev_upload(S, key, pk);
-}
-
 const float *packed_bias(EncState &S, const std::string &name, int cout_pad, bool has_bias)
 {
     const std::string key = name + "#b" + std::to_string(cout_pad);
@@ -681,29 +822,82 @@ const float *packed_bias(EncState &S, const std::string &name, int cout_pad, boo
     return dev_upload(S, key, b);
 }
 
-const short2 *taps_for(EncState &S, int k, int pad)
+// ---- LDS-DMA convolution path (k_prep_act + k_conv_dma) ---------------------------------------------------
+// one contiguous K run of the implicit GEMM: `nx` consecutive pixels of P starting at (dy, dx) relative to the row's base
+// pixel, pixel i of the run multiplying kernel tap (ky, kx[i])
+struct KSpan {
+    int dy = 0, dx = 0, nx = 0, ky = 0;
+    int kx[7] = {0};
+};
+
+// weights -> [cout_pad][sum over spans of roundup(nx * C, 32)], zero where a run is padded to the K step
+const float *packed_dma_weight(EncState &S, const std::string &key, const HostParam &w, bool transposed, int C, int cout,
+                               int cout_pad, const std::vector<KSpan> &spans, int *ldw_out)
 {
-    const std::string key = "#taps" + std::to_string(k) + "_" + std::to_string(pad);
-    if (!S.dev.count(key)) {
-        std::vector<float> packed(k * k);     // reinterpret as short2
-        short2 *t = reinterpret_cast<short2 *>(packed.data());
-        for (int dy = 0; dy < k; ++dy)
-            for (int dx = 0; dx < k; ++dx) t[dy * k + dx] = make_short2((short)(dy - pad), (short)(dx - pad));
-        dev_upload(S, key, packed);
+    int ldw = 0;
+    for (const KSpan &s : spans) ldw += (int)round_up((int64_t)s.nx * C, BK);
+    *ldw_out = ldw;
+    if (S.dev.count(key)) return S.dev[key];
+    const int d0 = (int)w.shape[0], d1 = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    const int ci = transposed ? d0 : d1;
+    if (ci > C) throw Fail{key + ": input channels exceed the prepared width"};
+    std::vector<float> pk((size_t)cout_pad * ldw, 0.f);
+    int base = 0;
+    for (const KSpan &s : spans) {
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < s.nx; ++i)
+                for (int c = 0; c < ci; ++c) {
+                    const size_t src = transposed ? ((((size_t)c * d1 + o) * kh + s.ky) * kw + s.kx[i])
+                                                  : ((((size_t)o * d1 + c) * kh + s.ky) * kw + s.kx[i]);
+                    pk[(size_t)o * ldw + base + i * C + c] = w.data[src];
+                }
+        base += (int)round_up((int64_t)s.nx * C, BK);
     }
-    return reinterpret_cast<const short2 *>(S.dev[key]);
+    return dev_upload(S, key, pk);
 }
 
-void launch_conv(EncState &S, ConvArgs a)
+// N tile of a DMA convolution: no wider than the output needs and never 128 - the 128 x 64 tile keeps three blocks per CU
+// (48 KB of LDS) and measured 129 TFLOP/s on a 128 -> 64 layer where the 128 x 128 tile (64 KB, two blocks) reached 70 on
+// 128 -> 128 - and narrower while that still helps to put ~2 tiles on every CU
+int pick_tile_n(int ntm, int cout, int nsteps)
+{
+    const int widest = cout > 32 ? 64 : 32;
+    if (widest == 64 && nsteps >= 96) return 64;      // deep K: split-K supplies the parallelism, the wider tile the MFMA rate
+    for (int tn = widest; tn >= 32; tn /= 2)
+        if ((int64_t)ntm * ((cout + tn - 1) / tn) >= 512 || tn == 32) return tn;
+    return 32;
+}
+
+// act(x) into the padded scratch image (one reusable buffer: launches are stream-ordered)
+float *prepare_input(EncState &S, const Tensor &x, const Affine &act, int Cp, int pad_lo, int Hp, int Wp, bool reflect,
+                     unsigned *bytes_out)
+{
+    const size_t floats = (size_t)Hp * Wp * Cp + 64;
+    if (floats * sizeof(float) >= ((size_t)1 << 32)) throw Fail{"prepared conv input exceeds 4 GB"};
+    if (pifu_ensure(S.prep, floats * sizeof(float)) != PIFU_OK) throw Fail{"prepared conv input allocation failed"};
+    PrepArgs p{};
+    p.X = x.p; p.H = x.H; p.W = x.W; p.ldx = x.ld;
+    p.scale = act.scale; p.shift = act.shift; p.slope = act.slope;
+    p.pad_lo = pad_lo; p.reflect = reflect ? 1 : 0;
+    p.P = static_cast<float *>(S.prep.p); p.Hp = Hp; p.Wp = Wp; p.Cp = Cp;
+    const size_t threads = (size_t)Hp * Wp * (Cp / 4) + 16;
+    hipLaunchKernelGGL(k_prep_act, dim3(nblk(threads, 256)), dim3(256), 0, S.st, p);
+    *bytes_out = (unsigned)(floats * sizeof(float));
+    return p.P;
+}
+
+// `stat` (may be null): receives the statistics partials of the stored values, if this launch can produce them (no split-K)
+void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr, int stat_class = 0, int stat_classes = 1)
 {
     a.ntm = (a.nrows + BM - 1) / BM;
-    a.ntn = (a.cout + BN - 1) / BN;
+    a.ntn = (a.cout + tn - 1) / tn;
+    a.ldp = a.ntn * tn;
     const int tiles = (int)round_up(a.ntm, 8) * a.ntn;
-    const int nsteps = a.ntaps * a.cin / BK;
-    // fewer than ~1 tile per CU: split K so that ~512 blocks are in flight, at least 8 K steps per split
+    const int nsteps = a.ldw / BK;
+    // fewer than ~1.5 tiles per CU: split K so that ~768 blocks are in flight, at least 8 K steps per split
     int nsplit = 1;
-    if (a.ntm * a.ntn < 192) {
-        nsplit = (512 + a.ntm * a.ntn - 1) / (a.ntm * a.ntn);
+    if (a.ntm * a.ntn < 384) {
+        nsplit = (768 + a.ntm * a.ntn - 1) / (a.ntm * a.ntn);
         if (nsplit > nsteps / 8) nsplit = nsteps / 8;
         if (nsplit < 1) nsplit = 1;
     }
@@ -713,81 +907,118 @@ void launch_conv(EncState &S, ConvArgs a)
     a.tiles_per_split = tiles;
     a.part = nullptr;
     if (nsplit > 1) {
-        const size_t bytes = (size_t)nsplit * a.ntm * BM * a.ntn * BN * sizeof(float);
+        const size_t bytes = (size_t)nsplit * a.ntm * BM * a.ldp * sizeof(float);
         if (pifu_ensure(S.splitk, bytes) != PIFU_OK) throw Fail{"split-K workspace allocation failed"};
         a.part = static_cast<float *>(S.splitk.p);
     }
-    hipLaunchKernelGGL(k_conv_gemm, dim3(tiles * nsplit), dim3(256), 0, S.st, a);
+    a.stat = nullptr;
+    a.stat_tile0 = 0;
+    if (stat && nsplit == 1 && S.fuse_stats) {
+        if (stat_class == 0) {
+            stat->stat_nb = a.ntm * stat_classes;
+            stat->stat = reinterpret_cast<double *>(arena_take(S, (size_t)stat->stat_nb * a.cout * 2 * 2));
+        }
+        a.stat = stat->stat;
+        a.stat_tile0 = stat_class * a.ntm;
+    } else if (stat) {
+        stat->stat = nullptr;
+        stat->stat_nb = 0;
+    }
+    const unsigned grid = (unsigned)tiles * nsplit;
+    if (tn == 64) hipLaunchKernelGGL(k_conv_dma<64>, dim3(grid), dim3(256), 0, S.st, a);
+    else hipLaunchKernelGGL(k_conv_dma<32>, dim3(grid), dim3(256), 0, S.st, a);
     if (nsplit > 1) {
-        const size_t threads = (size_t)a.nrows * (a.ntn * BN / 4);
-        hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.st, a);
+        const size_t threads = (size_t)a.nrows * (a.ldp / 4);
+        hipLaunchKernelGGL(k_conv_dma_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.st, a);
     }
 }
 
 // y (a channel slice of `out`) = conv(act(x)); out must have the conv's output size
 void conv2d(EncState &S, const std::string &wname, const std::string &bname, const Tensor &x, const Affine &act,
-            const ConvGeom &g, Tensor out, const Tensor *residual = nullptr)
+            const ConvGeom &g, Tensor &out, const Tensor *residual = nullptr)
 {
     if (x.ld % 4 || x.C % BK) throw Fail{wname + ": input channels must be padded to 32"};
-    int cout = 0, k = 0;
-    const int cout_pad = (int)round_up(out.C, BN);
-    const float *w = packed_conv_weight(S, wname, x.C, cout_pad, &cout, &k);
-    if (cout != out.C || k != g.k) throw Fail{wname + ": shape mismatch"};
-    ConvArgs a{};
-    a.X = x.p; a.Hin = x.H; a.Win = x.W; a.ldx = x.ld; a.cin = x.C;
-    a.scale = act.scale; a.shift = act.shift; a.slope = act.slope;
-    a.RW = out.W; a.nrows = out.H * out.W; a.os = 1; a.oy0 = 0; a.ox0 = 0; a.Wout = out.W; a.is = g.stride;
-    a.ntaps = g.k * g.k; a.taps = taps_for(S, g.k, g.pad); a.reflect = g.reflect ? 1 : 0;
-    a.W = w; a.bias = packed_bias(S, bname.empty() ? wname + "#nobias" : bname, cout_pad, !bname.empty());
-    a.Y = out.p; a.ldy = out.ld; a.cout = out.C;
-    if (residual) { a.R = residual->p; a.ldr = residual->ld; }
-    launch_conv(S, a);
+    const HostParam &wp = param(S, wname);
+    if (wp.shape.size() != 4) throw Fail{wname + ": expected a 4-d conv weight"};
+    const int co = (int)wp.shape[0], ci = (int)wp.shape[1], kk = (int)wp.shape[2];
+    if (co != out.C || kk != g.k) throw Fail{wname + ": shape mismatch"};
+    const int nrows = out.H * out.W;
+    if (g.k > CONV_MAX_SPANS) throw Fail{wname + ": kernel too large"};
+    {
+        // the packed network input and the padded `out` of a stack carry more channels than the weight reads: prepare
+        // only the channels that exist (rounded to the 16-byte chunk)
+        const int Cp = ci < x.C ? (int)round_up(ci, 4) : x.C;
+        const int tn = pick_tile_n((nrows + BM - 1) / BM, co, g.k * (int)round_up((int64_t)g.k * Cp, BK) / BK);
+        const int cout_pad = (int)round_up(co, tn);
+        const int Hp = std::max(x.H + 2 * g.pad, (out.H - 1) * g.stride + g.k), Wp = std::max(x.W + 2 * g.pad, (out.W - 1) * g.stride + g.k);
+        std::vector<KSpan> spans(g.k);
+        for (int ky = 0; ky < g.k; ++ky) {
+            spans[ky].dy = ky; spans[ky].dx = 0; spans[ky].nx = g.k; spans[ky].ky = ky;
+            for (int i = 0; i < g.k; ++i) spans[ky].kx[i] = i;
+        }
+        ConvDmaArgs a{};
+        a.W = packed_dma_weight(S, wname + "#dma" + std::to_string(Cp) + "_" + std::to_string(tn), wp, false, Cp, co, cout_pad, spans, &a.ldw);
+        a.bias = packed_bias(S, bname.empty() ? wname + "#nobias" : bname, cout_pad, !bname.empty());
+        a.P = prepare_input(S, x, act, Cp, g.pad, Hp, Wp, g.reflect, &a.p_bytes);
+        a.Wp = Wp; a.C = Cp; a.RW = out.W; a.nrows = nrows; a.is = g.stride;
+        a.nspan = g.k;
+        for (int ky = 0; ky < g.k; ++ky) {
+            a.span_off[ky] = ky * Wp * Cp * 4;
+            a.span_steps[ky] = (int)round_up((int64_t)g.k * Cp, BK) / BK;
+        }
+        a.Y = out.p; a.ldy = out.ld; a.cout = co;
+        if (residual) { a.R = residual->p; a.ldr = residual->ld; }
+        a.os = 1; a.oy0 = 0; a.ox0 = 0; a.Wout = out.W;
+        launch_conv_dma(S, a, tn, &out);
+    }
 }
 
 // ConvTranspose2d(k 3, stride 2, padding 1, output_padding 1) as 4 output-parity classes (networks.py:155-157)
 void conv_transpose2d(EncState &S, const std::string &wname, const std::string &bname, const Tensor &x, const Affine &act,
-                      Tensor out)
+                      Tensor &out)
 {
     const HostParam &w = param(S, wname);            // [Cin][Cout][3][3]
     const int ci = (int)w.shape[0], co = (int)w.shape[1];
     if (ci != x.C || co != out.C || out.H != 2 * x.H || out.W != 2 * x.W) throw Fail{wname + ": transposed conv shape mismatch"};
-    const int cout_pad = (int)round_up(co, BN);
-    const float *bias = packed_bias(S, bname, cout_pad, true);
-    for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-            // oy = 2 ry + py;  contributing ky: py == 0 -> {1 (iy = ry)},  py == 1 -> {0 (iy = ry + 1), 2 (iy = ry)}
-            int kys[2], iys[2], nky = 0, kxs[2], ixs[2], nkx = 0;
-            if (py == 0) { kys[nky] = 1; iys[nky++] = 0; } else { kys[nky] = 0; iys[nky++] = 1; kys[nky] = 2; iys[nky++] = 0; }
-            if (px == 0) { kxs[nkx] = 1; ixs[nkx++] = 0; } else { kxs[nkx] = 0; ixs[nkx++] = 1; kxs[nkx] = 2; ixs[nkx++] = 0; }
-            const int ntaps = nky * nkx;
-            const std::string key = wname + "#ct" + std::to_string(py) + std::to_string(px);
-            if (!S.dev.count(key)) {
-                std::vector<float> pk((size_t)cout_pad * ntaps * ci, 0.f), tp(ntaps);
-                short2 *t2 = reinterpret_cast<short2 *>(tp.data());
-                int t = 0;
-                for (int a = 0; a < nky; ++a)
-                    for (int b = 0; b < nkx; ++b, ++t) {
-                        t2[t] = make_short2((short)iys[a], (short)ixs[b]);
-                        for (int o = 0; o < co; ++o)
-                            for (int c = 0; c < ci; ++c)
-                                pk[((size_t)o * ntaps + t) * ci + c] = w.data[(((size_t)c * co + o) * 3 + kys[a]) * 3 + kxs[b]];
-                    }
-                dev_upload(S, key, pk);
-                dev_upload(S, key + ".t", tp);
+    {
+        // zero row / column behind the last pixel (the taps reach one pixel down / right), activation applied once
+        const int Cp = x.C, Hp = x.H + 1, Wp = x.W + 1;
+        const int tn = pick_tile_n((x.H * x.W + BM - 1) / BM, co, Cp / BK);
+        const int cout_pad = (int)round_up(co, tn);
+        const float *bias = packed_bias(S, bname, cout_pad, true);
+        unsigned p_bytes = 0;
+        const float *P = prepare_input(S, x, act, Cp, 0, Hp, Wp, false, &p_bytes);
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                // oy = 2 ry + py: input row ry uses ky = 1 (py == 0) or ky = 2 (py == 1); input row ry + 1 uses ky = 0 (py == 1)
+                std::vector<KSpan> spans;
+                for (int iy = 0; iy <= py; ++iy) {
+                    KSpan sp;
+                    sp.dy = iy; sp.dx = 0; sp.ky = py == 0 ? 1 : (iy == 0 ? 2 : 0);
+                    sp.nx = px + 1;
+                    for (int ix = 0; ix <= px; ++ix) sp.kx[ix] = px == 0 ? 1 : (ix == 0 ? 2 : 0);
+                    spans.push_back(sp);
+                }
+                ConvDmaArgs a{};
+                a.W = packed_dma_weight(S, wname + "#dmaT" + std::to_string(py) + std::to_string(px) + "_" + std::to_string(tn), w, true, Cp, co,
+                                        cout_pad, spans, &a.ldw);
+                a.bias = bias;
+                a.P = P; a.p_bytes = p_bytes; a.Wp = Wp; a.C = Cp; a.RW = x.W; a.nrows = x.H * x.W; a.is = 1;
+                a.nspan = (int)spans.size();
+                for (int i = 0; i < a.nspan; ++i) {
+                    a.span_off[i] = (spans[i].dy * Wp + spans[i].dx) * Cp * 4;
+                    a.span_steps[i] = (int)round_up((int64_t)spans[i].nx * Cp, BK) / BK;
+                }
+                a.Y = out.p; a.ldy = out.ld; a.cout = co;
+                a.os = 2; a.oy0 = py; a.ox0 = px; a.Wout = out.W;
+                launch_conv_dma(S, a, tn, &out, py * 2 + px, 4);
             }
-            ConvArgs a{};
-            a.X = x.p; a.Hin = x.H; a.Win = x.W; a.ldx = x.ld; a.cin = x.C;
-            a.scale = act.scale; a.shift = act.shift; a.slope = act.slope;
-            a.RW = x.W; a.nrows = x.H * x.W; a.os = 2; a.oy0 = py; a.ox0 = px; a.Wout = out.W; a.is = 1;
-            a.ntaps = ntaps; a.taps = reinterpret_cast<const short2 *>(S.dev[key + ".t"]); a.reflect = 0;
-            a.W = S.dev[key]; a.bias = bias; a.Y = out.p; a.ldy = out.ld; a.cout = co;
-            launch_conv(S, a);
-        }
+    }
 }
 
 // ---- building blocks -------------------------------------------------------------------------------------
 // ConvBlock (Filter.py:23-69): cat[conv1(a(bn1 x)), conv2(a(bn2 o1)), conv3(a(bn3 o2))] + (x | conv1x1(a(bn4 x)))
-Tensor conv_block(EncState &S, const std::string &p, const Tensor &x, int cout)
+Tensor conv_block(EncState &S, const std::string &p, Tensor x, int cout)
 {
     Tensor out = new_tensor(S, x.H, x.W, cout);
     const ConvGeom g3{3, 1, 1, false}, g1{1, 1, 0, false};
@@ -800,11 +1031,17 @@ Tensor conv_block(EncState &S, const std::string &p, const Tensor &x, int cout)
     Affine a3 = norm_affine(S, p + ".bn3", o2, S.norm); a3.slope = 0.f;
     conv2d(S, p + ".conv3.weight", "", o2, a3, g3, o3);
     if (x.C != cout) {
-        Affine a4 = norm_affine(S, p + ".bn4", x, S.norm); a4.slope = 0.f;
+        Affine a4 = norm_affine(S, p + ".bn4", x, S.norm); a4.slope = 0.f;      // same statistics as bn1: reduced once
         conv2d(S, p + ".downsample.2.weight", "", x, a4, g1, out, &out);      // out = conv1x1(...) + cat (in place)
-    } else {
+    } else if (S.norm == 0) {       // eval-mode BatchNorm: nobody needs statistics of the sum
         hipLaunchKernelGGL(k_add, dim3(nblk(out.pixels() * (cout / 4), 256)), dim3(256), 0, S.st, (const float *)out.p, out.ld,
                            (const float *)x.p, x.ld, (const float *)nullptr, (const float *)nullptr, out.p, out.ld, cout, out.pixels());
+    } else {                        // the next block normalises this sum: leave its statistics behind
+        const int P = (int)out.pixels(), rows_per_block = stat_rows_per_block(P);
+        out.stat_nb = (P + rows_per_block - 1) / rows_per_block;
+        out.stat = reinterpret_cast<double *>(arena_take(S, (size_t)out.stat_nb * cout * 2 * 2));
+        hipLaunchKernelGGL(k_add_stats, dim3(out.stat_nb), dim3(stat_threads(cout)), 0, S.st, (const float *)out.p, out.ld,
+                           (const float *)x.p, x.ld, out.p, out.ld, cout, P, rows_per_block, out.stat);
     }
     return out;
 }
@@ -985,6 +1222,7 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
     for (auto &kv : it->second->dev) (void)hipFree(kv.second);
     if (it->second->arena.p) (void)hipFree(it->second->arena.p);
     if (it->second->splitk.p) (void)hipFree(it->second->splitk.p);
+    if (it->second->prep.p) (void)hipFree(it->second->prep.p);
     delete it->second;
     g_states.erase(it);
     return PIFU_OK;
@@ -1006,12 +1244,14 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     try {
         if (use_front || use_back) {
             Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W);
+            S.fuse_stats = true;          // every conv of the normal nets is followed by an InstanceNorm
             if (use_front) { const size_t mark = S.used; global_generator(S, "netF", in, nmlF); S.used = mark; }
             if (use_back) { const size_t mark = S.used; global_generator(S, "netB", in, nmlB); S.used = mark; }
             S.used = 0;   // stream order keeps the reuse safe
         }
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W);
         S.norm = norm;
+        S.fuse_stats = norm != 0;         // eval-mode BatchNorm needs no statistics
         Tensor f = hg_filter(S, "image_filter", in, num_stack, hg_depth, hg_dim, ave_pool != 0);
         // install as the coarse query feature map (NHWC) and optionally export NCHW
         FeatMap &fm = ctx->feat[0];
@@ -1051,6 +1291,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     try {
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
         S.norm = norm;
+        S.fuse_stats = norm != 0;
         Tensor f = hg_filter(S, "fine.image_filter", in, num_stack, hg_depth, hg_dim, false);
         FeatMap &fm = ctx->feat[1];
         const size_t bytes = f.pixels() * f.C * sizeof(float);
