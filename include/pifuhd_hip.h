@@ -102,14 +102,15 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
  * pifu_filter_coarse = PIFuNetwNML.filter (PIFuNetwNML.py:73-97): img device NCHW [1][Cimg][H][W]; runs netF / netB
  * (networks.py:131-207) when enabled and writes their NCHW [1][3][H][W] outputs, then the HGFilter
  * (Filter.py:186-228) on cat[img, nmlF, nmlB]; the LAST stack's output becomes the coarse query feature map and is
- * optionally exported as NCHW [1][hg_dim][H/4][W/4] (ave_pool) to feat_nchw.
+ * optionally exported as NCHW [1][hg_dim][H/4][W/4] (ave_pool) to feat_nchw; with all_stacks != 0 (the module in train
+ * mode keeps the whole list, PIFuNetwNML.py:94-97) feat_nchw receives every stack's output, [num_stack][hg_dim][H/4][W/4].
  * pifu_filter_fine = PIFuMRNet.filter_local (PIFuMRNet.py:83-118, rect = None): normals (NCHW, Hn x Wn) are
  * resized bilinearly (align_corners) to H x W, concatenated, HGFilter('no_down'); output [1][hg_dim][H/2][W/2]. */
 int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
 int pifu_enc_clear(pifu_ctx *ctx);
 int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                        int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
-                       float *feat_nchw, pifu_stream stream);
+                       float *feat_nchw, int all_stacks, pifu_stream stream);
 int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF,
                      const float *nmlB, int Hn, int Wn, int num_stack, int hg_depth, int hg_dim, int norm,
                      float *feat_nchw, pifu_stream stream);
@@ -190,6 +191,23 @@ int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const
  * 2*size), BGR -> RGB, v/255, (t-0.5)/0.5.  bgr: device u8 [H][W][3]; out: device fp32 [3][size][size]. */
 int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
                           float *out, pifu_stream stream);
+
+/* ---- mesh clean-up of gen_mesh_imgColor_plus (reconstruction.py:127-229,325-344) ---------------------------------------
+ * pifu_face_components: connected components of a triangle list over shared edges - what `meshcleaning` obtains from
+ * trimesh's `mesh.split()` (reconstruction.py:331-332; trimesh is a third-party dependency absent from this image, its
+ * split semantics are restated: faces are adjacent when they share an edge that exactly two faces use).  faces: device
+ * int32 [nfaces][3]; label (device int32 [nfaces]) receives the SMALLEST face index of each face's component; open_edge
+ * (device uint8 [nfaces]) is 1 for faces with an edge that is not shared by exactly two faces (a component is watertight
+ * iff none of its faces is flagged).
+ * pifu_esti_color: `esti_color` (reconstruction.py:180-229), exact: xyz = projected vertices, device fp32 [3][n]; color:
+ * device uint16 [n][4] (RGBA), updated in place - every vertex with z < 0 receives the mean (uint16 sums, float64 division,
+ * truncation) of the colours of its <= 10 nearest silhouette vertices (0 <= z < 0.001) on the left (x_s < x: ordered by
+ * |y_s - y| ascending, x_s descending) and <= 10 on the right (x_s >= x: |y_s - y| ascending, x_s ascending), ties in
+ * vertex order.  Fails with PIFU_ERR_STATE where the reference raises (no silhouette vertex at all / none on either side).
+ * Synchronises the stream. */
+int pifu_face_components(pifu_ctx *ctx, const int32_t *faces, int64_t nfaces, int32_t *label, uint8_t *open_edge,
+                         pifu_stream stream);
+int pifu_esti_color(pifu_ctx *ctx, const float *xyz, int64_t n, uint16_t *color, pifu_stream stream);
 
 /* ---- supervised forward: CustomBCELoss.forward (net_util.py:45-66) as used by PIFuMRNet.get_error (PIFuMRNet.py:253-274).
  * Forward value only (the HIP path has no autograd): mean over [batch][n] of

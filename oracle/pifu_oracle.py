@@ -118,11 +118,13 @@ def effective_merge_layer(merge_layer, dims):
 class OracleNets:
     """Holds the state dict + feature maps; mirrors the call order filter -> query -> get_preds."""
 
-    def __init__(self, sd, opt_coarse, opt_fine=None, fine_training=True):
+    def __init__(self, sd, opt_coarse, opt_fine=None, fine_training=True, coarse_training=False):
         self.sd = sd
         self.oc = opt_coarse
         self.of = opt_fine
         self.fine_training = fine_training          # SURVEY C-2: recon() leaves netMR in train mode
+        self.coarse_training = coarse_training      # train_full_pifu: netG in train mode keeps every stack (PIFuNetwNML.py:94-97)
+        self.feat_coarse_stacks = None
         self.feat_coarse = None
         self.feat_fine = None
         self.nmlF = None
@@ -178,6 +180,27 @@ class OracleNets:
         return {'preds': preds, 'preds_low': preds_low, 'labels': newlabels, 'w': w, 'gamma': gamma,
                 'err_fine': err, 'coarse_labels': xyz_in * labels}
 
+    def query_supervised_full_pifu(self, points, calib, labels):
+        """`train_full_pifu`: `netG.query` on every kept stack (`PIFuNetwNML.py:124-134`), `preds_low` = their stack,
+        `Err(occ)` = mean loss over the stacks, `Err(occ:fine)` over preds_interm's length reading preds_low
+        (`PIFuMRNet.py:154-155,255-270`).  The fine level consumes the LAST stack's phi."""
+        xyz = orthogonal(points, calib)
+        inside = ((xyz[:, :2] >= -1) & (xyz[:, :2] <= 1)).all(dim=1, keepdim=True).float()
+        lows = []
+        last = self.feat_coarse
+        for f in self.feat_coarse_stacks:
+            self.feat_coarse = f
+            lows.append(self.query_coarse(points, calib)[0])
+        self.feat_coarse = last
+        preds = self.query(points, calib)
+        newlabels = inside * labels
+        w = inside.size(2) / inside.view(inside.size(0), -1).sum(1)
+        gamma = 1 - newlabels.view(newlabels.size(0), -1).sum(1) / inside.view(inside.size(0), -1).sum(1)
+        preds_low = torch.stack(lows, 0)
+        err_occ = sum(custom_bce_loss(p_, newlabels, gamma, w) for p_ in preds_low) / preds_low.size(0)
+        err_fine = custom_bce_loss(preds_low[0], newlabels, gamma, w)
+        return {'preds': preds, 'preds_low': preds_low, 'err_occ': err_occ, 'err_fine': err_fine}
+
     # ---- A17 ------------------------------------------------------------------------------
     def calc_normal(self, points, calib, delta=0.001):
         """Forward differences (`PIFuMRNet.py:188-243`); points [1,3,n] -> [1,3,n]."""
@@ -203,8 +226,9 @@ class OracleNets:
             imgs.append(self.nmlB)
         x = torch.cat(imgs, 1)
         outs, _ = hg_filter(self.sd, 'netG.image_filter', x, oc.num_stack, oc.hg_depth, oc.norm,
-                            oc.hg_down, bn_training=False)
+                            oc.hg_down, bn_training=self.coarse_training)
         self.feat_coarse = outs[-1]                      # eval mode keeps the last stack only
+        self.feat_coarse_stacks = outs if self.coarse_training else None
         return self.feat_coarse
 
     def filter_local(self, img):
@@ -505,6 +529,61 @@ def obj_text(verts, faces, colors) -> str:
              for v, c in zip(verts, colors)]
     lines += ['f %d %d %d\n' % (f[0] + 1, f[2] + 1, f[1] + 1) for f in faces]
     return ''.join(lines)
+
+
+def esti_color(color: np.ndarray, xyz: np.ndarray) -> np.ndarray:
+    """`esti_color` (`reconstruction.py:180-229`): color uint16 [V,4], xyz float32 [V,3] (projected vertices).  Every vertex
+    with z < 0 takes the mean colour of its (at most) ten nearest silhouette vertices (0 <= z < 0.001) on the left
+    (x_s < x; |dy| ascending, then x descending) and ten on the right (x_s >= x; |dy| ascending, then x ascending); equal
+    keys keep vertex order.  uint16 sums, float64 division, truncation on store."""
+    xyz32 = np.asarray(xyz, dtype=np.float32)
+    out = np.array(color, dtype=np.uint16, copy=True)
+    z = xyz32[:, 2]
+    sil = np.flatnonzero((z >= np.float32(0)) & (z < np.float32(0.001)))
+    if len(sil) == 0:
+        raise IndexError('no silhouette vertex')
+    X = xyz32.astype(np.float64)
+    for i in np.flatnonzero(z < np.float32(0)):
+        dx = X[sil, 0] - X[i, 0]
+        dy = np.abs(X[sil, 1] - X[i, 1])
+        L, R = sil[dx < 0], sil[dx >= 0]
+        dL, dR = dy[dx < 0], dy[dx >= 0]
+        oL = np.lexsort((np.arange(len(L)), -X[L, 0], dL))[:10]            # last key is the primary one
+        oR = np.lexsort((np.arange(len(R)), X[R, 0], dR))[:10]
+        if len(oL) + len(oR) == 0:
+            raise Exception('no colour source')
+        total = np.zeros(4, dtype=np.uint16)
+        for idx in list(L[oL]) + list(R[oR]):
+            total = (total + out[idx]).astype(np.uint16)
+        out[i] = (total / float(len(oL) + len(oR))).astype(np.uint16)
+    return out
+
+
+def face_components(faces: np.ndarray):
+    """Edge-connected components of a triangle list (faces adjacent iff they share an edge used by exactly two faces):
+    returns (label = smallest face index of the component, per face; open = the face has an edge not used by exactly
+    two faces).  Plain union-find; the checker of `pifu_face_components`."""
+    F = np.asarray(faces, dtype=np.int64)
+    edges = {}
+    for f, (a, b, c) in enumerate(F):
+        for u, v in ((a, b), (b, c), (c, a)):
+            edges.setdefault((min(u, v), max(u, v)), []).append(f)
+    parent = list(range(len(F)))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    open_face = np.zeros(len(F), dtype=np.uint8)
+    for fs in edges.values():
+        if len(fs) == 2:
+            a, b = find(fs[0]), find(fs[1])
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+        else:
+            open_face[fs] = 1
+    return np.array([find(f) for f in range(len(F))], dtype=np.int32), open_face
 
 
 def analytic_field(points: np.ndarray) -> np.ndarray:

@@ -46,7 +46,7 @@ SIGNATURES = {
     'pifu_set_features': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
     'pifu_enc_set_param': (_i32, [_p, C.c_char_p, _p, _p, _i32]),
     'pifu_enc_clear': (_i32, [_p]),
-    'pifu_filter_coarse': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    'pifu_filter_coarse': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'pifu_filter_fine': (_i32, [_p, _p, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'pifu_query': (_i32, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
     'pifu_eval_lattice': (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _p]),
@@ -60,6 +60,8 @@ SIGNATURES = {
     'pifu_calc_normal_chunked': (_i32, [_p, _p, _i64, _i64, _p, _f, _p, _p, _p]),
     'pifu_index': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),
+    'pifu_face_components': (_i32, [_p, _p, _i64, _p, _p, _p]),
+    'pifu_esti_color': (_i32, [_p, _p, _i64, _p, _p]),
     'pifu_bce_loss': (_i32, [_p, _p, _p, _i32, _i64, _p, _f, _p, _i32, _i32, _p, _p]),
     'pifu_profile_enable': (_i32, [_p, _i32]),
     'pifu_profile_read': (_i32, [_p, _i32, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),

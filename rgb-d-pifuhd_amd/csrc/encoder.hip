@@ -1068,7 +1068,8 @@ Tensor hourglass(EncState &S, const std::string &p, int level, const Tensor &x)
 }
 
 // Filter.forward (Filter.py:186-228); returns the LAST stack's output (what inference keeps)
-Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_stack, int depth, int last_ch, bool ave_pool)
+Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_stack, int depth, int last_ch, bool ave_pool,
+                 std::vector<Tensor> *stacks = nullptr)
 {
     const ConvGeom g1{1, 1, 0, false};
     const int H1 = (in32.H + 2 * 3 - 7) / 2 + 1, W1 = (in32.W + 2 * 3 - 7) / 2 + 1;
@@ -1096,6 +1097,7 @@ Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_st
         if (lc_pad != last_ch) (void)hipMemsetAsync(out.p, 0, out.pixels() * lc_pad * sizeof(float), S.st);
         Tensor out_valid = out; out_valid.C = last_ch;
         conv2d(S, p + ".l" + ss + ".weight", p + ".l" + ss + ".bias", cl, be, g1, out_valid);
+        if (stacks) stacks->push_back(out_valid);                                            // train mode keeps every stack's output
         if (s < n_stack - 1) {
             Tensor t1 = new_tensor(S, ll.H, ll.W, 256), t2 = new_tensor(S, ll.H, ll.W, 256);
             conv2d(S, p + ".bl" + ss + ".weight", p + ".bl" + ss + ".bias", cl, be, g1, t1, &prev);   // previous + bl(ll)
@@ -1231,7 +1233,7 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
 // PIFuNetwNML.filter (PIFuNetwNML.py:73-97)
 extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                                   int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
-                                  float *feat_nchw, pifu_stream stream)
+                                  float *feat_nchw, int all_stacks, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && img_nchw, PIFU_ERR_INVALID, "pifu_filter_coarse: null argument");
     PIFU_REQUIRE(H % 16 == 0 && W % 16 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_coarse: H, W must be multiples of 16");
@@ -1252,7 +1254,8 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W);
         S.norm = norm;
         S.fuse_stats = norm != 0;         // eval-mode BatchNorm needs no statistics
-        Tensor f = hg_filter(S, "image_filter", in, num_stack, hg_depth, hg_dim, ave_pool != 0);
+        std::vector<Tensor> stacks;
+        Tensor f = hg_filter(S, "image_filter", in, num_stack, hg_depth, hg_dim, ave_pool != 0, &stacks);
         // install as the coarse query feature map (NHWC) and optionally export NCHW
         FeatMap &fm = ctx->feat[0];
         const size_t bytes = f.pixels() * f.C * sizeof(float);
@@ -1265,7 +1268,11 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
                                   hipMemcpyDeviceToDevice, S.st));
-        if (feat_nchw)
+        if (feat_nchw && all_stacks) {      // train mode (PIFuNetwNML.py:94-97 keeps the whole list): [num_stack][C][H/4][W/4]
+            for (size_t k = 0; k < stacks.size(); ++k)
+                hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)stacks[k].p,
+                                   stacks[k].ld, f.C, (int)f.pixels(), feat_nchw + k * f.pixels() * f.C);
+        } else if (feat_nchw)
             hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)f.p, f.ld, f.C,
                                (int)f.pixels(), feat_nchw);
     } catch (const Fail &e) {

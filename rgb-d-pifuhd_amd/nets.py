@@ -276,9 +276,6 @@ class PIFuNetwNML(BasePIFuNet):
         images = images.to(self.device, torch.float32).contiguous()
         if images.dim() != 4 or images.shape[0] != 1:
             raise NotImplementedError('images [1,C,H,W] (batch size 1, the reconstruction path)')
-        if self.training:
-            raise NotImplementedError('coarse-level filter() in train mode (all stacks, train-mode norms) is a training-'
-                                      'time path; recon() always calls netG.eval() first (reconstruction.py:288-289)')
         o = self.opt
         _, cimg, h, w = images.shape
         if o.hg_down != 'ave_pool':
@@ -288,11 +285,14 @@ class PIFuNetwNML(BasePIFuNet):
         use_f, use_b = self.netF is not None, self.netB is not None
         self.nmlF = torch.empty(1, 3, h, w, device=self.device) if use_f else None
         self.nmlB = torch.empty(1, 3, h, w, device=self.device) if use_b else None
-        feat = torch.empty(1, o.hg_dim, h // 4, w // 4, device=self.device)
+        # train mode (train_full_pifu): BatchNorm2d of the HGFilter on batch statistics and EVERY stack's output kept
+        # (PIFuNetwNML.py:94-97); eval mode: running statistics, last stack only
+        stacks = int(o.num_stack) if self.training else 1
+        feat = torch.empty(stacks, o.hg_dim, h // 4, w // 4, device=self.device)
         _lib.call('pifu_filter_coarse', self._ctx.h, _ptr(images), cimg, h, w, int(o.num_stack), int(o.hg_depth),
-                  int(o.hg_dim), _ENC_NORM[(o.norm, False)], 1, int(use_f), int(use_b), _ptr(self.nmlF), _ptr(self.nmlB),
-                  _ptr(feat), _stream_ptr(self.device))
-        self.im_feat_list = [feat]          # eval mode keeps the last stack only (PIFuNetwNML.py:96-97)
+                  int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1, int(use_f), int(use_b), _ptr(self.nmlF),
+                  _ptr(self.nmlB), _ptr(feat), int(self.training), _stream_ptr(self.device))
+        self.im_feat_list = [feat[k:k + 1] for k in range(stacks)]
         self.normx = None                   # never read on the reconstruction path
 
     def _set_features(self, feat):
@@ -319,11 +319,20 @@ class PIFuNetwNML(BasePIFuNet):
             raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
         n = pts.shape[2]
         calib, calib_p = _host_f32(calibs[0])
-        pred = torch.empty(n, device=self.device, dtype=torch.float32)
         cphi = self.opt.mlp_dim[(self.opt.merge_layer if self.opt.merge_layer > 0 else len(self.opt.mlp_dim) // 2) + 1]
         phi = torch.empty(cphi, n, device=self.device, dtype=torch.float32) if update_phi else None
-        _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, _lib.Q_COARSE_ONLY, None, _ptr(pred),
-                  _ptr(phi), _stream_ptr(self.device))
+        # one pass of the (shared) MLP per kept stack (PIFuNetwNML.py:124-134): all of them in train mode, the last one
+        # otherwise; phi is the last stack's.  The context ends up holding the LAST stack's map, which is what the fine
+        # level's own coarse pass must see.
+        preds = []
+        for k, feat in enumerate(self.im_feat_list):
+            last = k == len(self.im_feat_list) - 1
+            if len(self.im_feat_list) > 1:
+                self._set_features(feat)
+            pred = torch.empty(n, device=self.device, dtype=torch.float32)
+            _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, _lib.Q_COARSE_ONLY, None, _ptr(pred),
+                      _ptr(phi) if last else None, _stream_ptr(self.device))
+            preds.append(pred[None, None])
         if labels is not None:                                  # PIFuNetwNML.py:115-120: in-box over x, y and z
             xyz = self.projection(pts, calibs.to(self.device, torch.float32))
             in_bb = ((xyz >= -1) & (xyz <= 1)).all(dim=1, keepdim=True).float()
@@ -331,8 +340,8 @@ class PIFuNetwNML(BasePIFuNet):
         if update_phi:
             self.phi = phi[None]
         if update_pred:
-            self.preds = pred[None, None]
-            self.intermediate_preds_list = [self.preds]
+            self.preds = preds[-1]
+            self.intermediate_preds_list = preds
 
 
 class PIFuMRNet(BasePIFuNet):
@@ -480,15 +489,22 @@ class PIFuMRNet(BasePIFuNet):
         g = self.netG
         cphi = g.opt.mlp_dim[(g.opt.merge_layer if g.opt.merge_layer > 0 else len(g.opt.mlp_dim) // 2) + 1]
         phi = torch.empty(cphi, n, device=self.device, dtype=torch.float32)
+        if len(g.im_feat_list) > 1:
+            # train_full_pifu: netG kept every stack; its query runs the MLP on each of them (PIFuMRNet.py:154-155) and
+            # leaves the last stack's map installed, which the fused coarse + fine pass below then reads
+            g.query(pts, calib_local)
+            earlier = g.intermediate_preds_list[:-1]
+        else:
+            earlier = []
         _lib.call('pifu_query', self._ctx.h, _ptr(pts), n, calib_p, n, 0, _ptr(fine), _ptr(coarse), _ptr(phi),
                   _stream_ptr(self.device))
         # attributes the reference leaves behind (PIFuMRNet.py:154-181, PIFuNetwNML.py:137-141)
         g.phi = phi[None]
         g.preds = coarse[None, None]
-        g.intermediate_preds_list = [g.preds]
+        g.intermediate_preds_list = earlier + [g.preds]
         self.preds = fine[None, None]
         self.preds_interm = self.preds[None]
-        self.preds_low = g.preds[None]
+        self.preds_low = torch.stack(g.intermediate_preds_list, 0)
         if labels is not None:                                  # PIFuMRNet.py:157-162,183-186
             lab = labels.to(self.device, torch.float32)
             if lab.dim() == 4:

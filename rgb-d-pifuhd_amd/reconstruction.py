@@ -168,10 +168,115 @@ def gen_mesh_imgColor(res, net, cuda, data, save_path, thresh=0.5, use_octree=Tr
 # ------------------------------------------------------------------------------------------------
 # Checkpoints and the recon() driver (reconstruction.py:232-321)
 # ------------------------------------------------------------------------------------------------
+def read_obj_with_color(path):
+    """Parse an OBJ as `save_obj_mesh_with_color` writes it ('v x y z r g b' / 'f a b c', 1-based): returns
+    (verts float64 [V,3], colours float64 [V,3], faces int32 [F,3] in file order)."""
+    v, f = [], []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith('v '):
+                v.append(line.split()[1:7])
+            elif line.startswith('f '):
+                f.append([t.split('/')[0] for t in line.split()[1:4]])
+    va = np.asarray(v, dtype=np.float64).reshape(-1, 6)
+    return va[:, :3].copy(), va[:, 3:6].copy(), np.asarray(f, dtype=np.int64).reshape(-1, 3).astype(np.int32) - 1
+
+
+def largest_component(verts, faces, device):
+    """Face indices (ascending) of the component `meshcleaning` keeps (`reconstruction.py:331-342`): of the WATERTIGHT
+    edge-connected components (trimesh's `mesh.split()` default), the one with the largest extent along axis 0; the first
+    one wins ties.  Components come from the device union-find `pifu_face_components`.  Raises IndexError when no
+    component is watertight (`cc[0]` on an empty list in the reference)."""
+    import ctypes as C
+
+    from . import _lib
+    from .net_util import _ctx_cache
+    from .nets import _ptr, _stream_ptr
+    dev = torch.device(device)
+    ctx = _ctx_cache(dev)
+    fd = torch.from_numpy(np.ascontiguousarray(faces, dtype=np.int32)).to(ctx.device)
+    label = torch.empty(len(faces), device=ctx.device, dtype=torch.int32)
+    open_edge = torch.empty(len(faces), device=ctx.device, dtype=torch.uint8)
+    _lib.call('pifu_face_components', ctx.h, _ptr(fd), len(faces), _ptr(label), _ptr(open_edge), _stream_ptr(ctx.device))
+    label, open_edge = label.cpu().numpy(), open_edge.cpu().numpy().astype(bool)
+    roots, inv = np.unique(label, return_inverse=True)            # ascending root = ascending first face: trimesh's order
+    leaky = np.zeros(len(roots), bool)
+    np.logical_or.at(leaky, inv, open_edge)
+    x = verts[:, 0][faces]                                       # [F, 3]
+    lo = np.full(len(roots), np.inf)
+    hi = np.full(len(roots), -np.inf)
+    np.minimum.at(lo, inv, x.min(1))
+    np.maximum.at(hi, inv, x.max(1))
+    best, best_extent = -1, None
+    for c in np.flatnonzero(~leaky):
+        extent = hi[c] - lo[c]
+        if best < 0 or best_extent < extent:
+            best, best_extent = c, extent
+    if best < 0:
+        raise IndexError('list index out of range')
+    return np.flatnonzero(inv == best)
+
+
+def meshcleaning(obj_path, device='cuda'):
+    """`meshcleaning` (`reconstruction.py:325-344`): keep the connected component with the largest extent along axis 0
+    and rewrite the file.  The OBJ is read back as written (4 decimals), vertices no face of the component references are
+    dropped (order kept), faces keep their file order.  Returns (verts, colours uint8 RGBA, faces) of the kept component;
+    colours take trimesh's float -> uint8 route (round(c * 255), alpha 255) - trimesh is absent here, so its loader's
+    behaviour is restated, not pinned."""
+    print(f'Processing mesh cleaning: {obj_path}')
+    verts, colours, faces = read_obj_with_color(obj_path)
+    keep = largest_component(verts, faces, device)
+    used = np.unique(faces[keep])
+    remap = np.full(len(verts), -1, np.int64)
+    remap[used] = np.arange(len(used))
+    verts, faces = verts[used], remap[faces[keep]].astype(np.int32)
+    rgba = np.concatenate([np.clip(np.rint(colours[used] * 255.0), 0, 255), np.full((len(used), 1), 255.0)], 1).astype(np.uint8)
+    _write_obj_plain(obj_path, verts, faces, rgba[:, :3] / 255.0)
+    return verts, rgba, faces
+
+
+def _write_obj_plain(path, verts, faces, colours):
+    """An OBJ with the faces in the order given (the native writer swaps the last two indices, as
+    `save_obj_mesh_with_color` does; a mesh read back from such a file is written back unswapped)."""
+    save_obj_mesh_with_color(path, verts, faces[:, [0, 2, 1]], colours)
+
+
+def esti_color(color, xyz_tensor):
+    """`esti_color` (`reconstruction.py:180-229`): color uint16 [V,4], xyz_tensor [1,3,V] (projected vertices); returns the
+    colour array with every back-side vertex (z < 0) recoloured from the silhouette.  Runs in `pifu_esti_color`."""
+    from . import _lib
+    from .net_util import _ctx_cache
+    from .nets import _ptr, _stream_ptr
+    xyz = xyz_tensor[0].to(torch.float32).contiguous()
+    if not xyz.is_cuda:
+        raise _lib.PifuError(_lib.ERR_INVALID, 'the HIP path needs device tensors (no CPU fallback)')
+    ctx = _ctx_cache(xyz.device)
+    # uint16 storage travels as int16 (torch has no arithmetic on uint16): same bits
+    col = torch.from_numpy(np.ascontiguousarray(color, dtype=np.uint16).view(np.int16)).to(xyz.device)
+    try:
+        _lib.call('pifu_esti_color', ctx.h, _ptr(xyz), xyz.shape[1], _ptr(col), _stream_ptr(ctx.device))
+    except _lib.PifuError as e:
+        raise Exception(e.message)                      # the reference raises a bare Exception / IndexError here
+    return col.cpu().numpy().view(np.uint16)
+
+
 def gen_mesh_imgColor_plus(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False):
     """`gen_mesh_imgColor_plus` (`reconstruction.py:127-178`): the image-coloured mesh, reduced to its widest connected
-    component and with the back side recoloured from the silhouette."""
-    raise NotImplementedError('gen_mesh_imgColor_plus (mesh cleaning + back-side recolouring) is not built yet')
+    component (`meshcleaning`), back side recoloured from the silhouette (`esti_color`), written back to `save_path`.
+    Failures after the encoders are printed ('error' + the exception), as in the reference."""
+    subj = _Subject(net, data)
+    try:
+        verts, faces, colour = _image_coloured_mesh(subj, res, net, cuda, data, save_path, thresh, use_octree)
+        save_obj_mesh_with_color(save_path, verts, faces, colour)
+        verts, rgba, faces = meshcleaning(save_path, net.device)
+        on_device = torch.from_numpy(verts.T).unsqueeze(0).to(device=net.device).float()
+        rgba = np.array(esti_color(np.array(rgba, dtype='uint16'), net.projection(on_device, subj.calib[:1])), dtype='uint8')
+        _write_obj_plain(save_path, verts, faces, rgba[:, :3] / 255.0)
+        return verts, faces, rgba
+    except Exception as e:
+        print('error')
+        print(e)
+        return None
 
 
 def load_checkpoint(path, map_location='cpu'):

@@ -405,3 +405,41 @@ def test_query_with_nontrivial_calibrations(golden_dir, tag):
     assert np.abs(outs[0] - outs[1]).max() < 2e-5
     if tag == 'rot_y':
         assert np.array_equal(outs[0], outs[1])             # x depends on z: both runs take the per-point path
+
+
+def test_full_pifu_supervised_forward_all_stacks(golden_dir):
+    """`opt.train_full_pifu`: netG stays in train mode, its HGFilter runs on batch statistics and keeps
+    every stack (`PIFuNetwNML.py:94-97`), `netG.query` evaluates the MLP on each stack, `preds_low` stacks the results and
+    `get_error` adds `Err(occ)` over them (`PIFuMRNet.py:154-155,255-270`).  Fixture from the imported reference."""
+    from pifuhd_amd import nets, synth
+    gold = np.load(os.path.join(golden_dir, 'labels_full_pifu.npz'))
+    seed, n = [int(v) for v in gold['seed']]
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(1, 3, n, generator=g) * 2.2 - 1.1
+    labels = (torch.rand(1, 1, n, generator=g) > 0.5).float()
+    sd, oc, of = golden_nets()
+    oc.train_full_pifu = True
+    of.train_full_pifu = True
+    of.no_intermediate_loss = False
+    of.loadSizeBig = 128
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    netMR = nets.PIFuMRNet(of, netG)
+    netMR.load_state_dict(sd)
+    netMR.train()
+    assert netG.training and netMR.training
+    netMR.filter_global(synth.synthetic_image(64, 3, seed=2))
+    netMR.filter_local(synth.synthetic_image(128, 3, seed=3)[:, None])
+    assert len(netG.im_feat_list) == 4
+    stacks = torch.cat(netG.im_feat_list, 0).cpu().numpy()
+    assert np.abs(stacks - gold['feat_stacks']).max() < 2e-4 * max(np.abs(gold['feat_stacks']).max(), 1.0)
+    netMR.query(pts, calib_tensor(), labels=labels)
+    assert netMR.preds_low.shape == (4, 1, 1, n)
+    assert np.abs(netMR.preds_low.cpu().numpy() - gold['preds_low']).max() < TOL
+    assert np.abs(netMR.preds.cpu().numpy() - gold['preds']).max() < TOL
+    err = netMR.get_error()
+    assert abs(float(err['Err(occ)']) - float(gold['err_occ'][0])) < 1e-4
+    assert abs(float(err['Err(occ:fine)']) - float(gold['err_fine'][0])) < 1e-4
+    # back in eval mode the coarse net keeps the last stack only and folds its running statistics again
+    netG.eval()
+    netMR.filter_global(synth.synthetic_image(64, 3, seed=2))
+    assert len(netG.im_feat_list) == 1

@@ -43,3 +43,27 @@ def test_custom_bce_loss_matches_reference():
     assert np.allclose(got, gold['loss_plain'], rtol=1e-6)
     got = [float(O.custom_bce_loss(pred, gt, gam, w, brock=True)), float(O.custom_bce_loss(pred, gt, gam, w, fixed_gamma=0.25))]
     assert np.allclose(got, gold['loss_brock'], rtol=1e-6)
+
+
+def test_full_pifu_supervised_forward_matches_reference():
+    """train_full_pifu: coarse HGFilter in train mode (batch statistics, every stack kept), MLP on every stack, Err(occ)
+    over the stacks - oracle against the fixture from the imported reference (make_golden_labels.py full)."""
+    from pifuhd_amd import synth
+    gold = np.load(os.path.join(os.path.dirname(GOLD), 'labels_full_pifu.npz'))
+    seed, n = [int(v) for v in gold['seed']]
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(1, 3, n, generator=g) * 2.2 - 1.1
+    labels = (torch.rand(1, 1, n, generator=g) > 0.5).float()
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    nets = O.OracleNets(sd, oc, of, fine_training=True, coarse_training=True)
+    with torch.no_grad():
+        nets.filter_global(synth.synthetic_image(64, 3, seed=2))
+        nets.filter_local(synth.synthetic_image(128, 3, seed=3))
+        r = nets.query_supervised_full_pifu(pts, calib_tensor(), labels)
+    stacks = torch.cat(nets.feat_coarse_stacks, 0).numpy()
+    assert np.abs(stacks - gold['feat_stacks']).max() < 1e-4 * max(np.abs(gold['feat_stacks']).max(), 1.0)
+    assert np.abs(r['preds_low'].numpy() - gold['preds_low']).max() < 1e-4
+    assert np.abs(r['preds'].numpy() - gold['preds']).max() < 1e-4
+    assert abs(float(r['err_occ']) - float(gold['err_occ'][0])) < 1e-5
+    assert abs(float(r['err_fine']) - float(gold['err_fine'][0])) < 1e-5
