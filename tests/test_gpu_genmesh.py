@@ -233,10 +233,79 @@ def test_face_components_against_the_oracle():
     assert np.array_equal(open_edge.cpu().numpy(), want_open)
 
 
-def test_gen_mesh_imgcolor_plus(tmp_path, capsys):
-    """`gen_mesh_imgColor_plus` (`reconstruction.py:127-178`): image-coloured mesh -> widest watertight component ->
-    back side recoloured from the silhouette.  Each stage is compared with the oracle on the same intermediate."""
+def _plus_oracle(base_obj, calib):
+    """gen_mesh_imgColor_plus after the image-coloured OBJ exists, restated with the oracle: returns (verts, faces, rgba)
+    or the exception the pipeline ends with."""
     from oracle import pifu_oracle as O
+    from pifuhd_amd import reconstruction
+    v0, c0, f0 = reconstruction.read_obj_with_color(base_obj)
+    lab, open_face = O.face_components(f0)
+    best, best_ext = None, None
+    for r in np.unique(lab):
+        sel = lab == r
+        if open_face[sel].any():
+            continue
+        ext = np.ptp(v0[:, 0][f0[sel]])
+        if best is None or best_ext < ext:
+            best, best_ext = r, ext
+    if best is None:
+        return IndexError('list index out of range')
+    used = np.unique(f0[lab == best])
+    remap = np.full(len(v0), -1)
+    remap[used] = np.arange(len(used))
+    verts, faces = v0[used], remap[f0[lab == best]]
+    rgba0 = np.concatenate([np.clip(np.rint(c0[used] * 255.0), 0, 255), np.full((len(used), 1), 255.0)], 1).astype(np.uint16)
+    xyz = O.orthogonal(torch.from_numpy(verts.T).float()[None], calib)[0].numpy().T
+    try:
+        return verts, faces, O.esti_color(rgba0, xyz).astype(np.uint8)
+    except Exception as e:
+        return e
+
+
+def test_meshcleaning_and_recolouring_on_analytic_bodies(tmp_path):
+    """meshcleaning + esti_color on a mesh with known structure: a wide closed ellipsoid, a taller but narrower closed one,
+    and a sheet cut open by the volume border (wider than both, but not watertight: trimesh's split() drops it)."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util, reconstruction
+    from pifuhd_amd.nets import _Ctx
+    R = 64
+    lin = -1 + 2 * np.arange(R) / R
+    X, Y, Z = np.meshgrid(lin, lin, lin, indexing='ij')
+    wide = 1 - np.sqrt(((X + 0.1) / 0.55) ** 2 + ((Y - 0.45) / 0.2) ** 2 + (Z / 0.3) ** 2)
+    tall = 1 - np.sqrt(((X - 0.3) / 0.2) ** 2 + ((Y + 0.35) / 0.4) ** 2 + (Z / 0.25) ** 2)
+    sheet = 0.03 - np.abs(Y + 0.85)
+    vol = (0.5 + 0.5 * np.maximum(np.maximum(wide, tall), sheet * 10)).astype(np.float32)
+    v, f = mesh_util.marching_cubes_device(_Ctx('cuda'), torch.from_numpy(vol).cuda(), 0.5)
+    verts = v.cpu().numpy().astype(np.float64) * (2.0 / R) - 1.0
+    faces = f.cpu().numpy()
+    rs = np.random.RandomState(2)
+    colour = rs.rand(len(verts), 3)
+    base = str(tmp_path / 'bodies.obj')
+    mesh_util.save_obj_mesh_with_color(base, verts, faces, colour)
+    want = _plus_oracle(base, calib_tensor())
+    assert not isinstance(want, Exception)
+    kept_v, kept_rgba, kept_f = reconstruction.meshcleaning(base, 'cuda')
+    assert np.array_equal(kept_v, want[0]) and np.array_equal(kept_f, want[1])
+    assert kept_v[:, 1].min() > 0.2 and np.ptp(kept_v[:, 0]) > 1.0              # the wide ellipsoid, not the tall one, not the sheet
+    xyz = O.orthogonal(torch.from_numpy(kept_v.T).float()[None], calib_tensor())
+    got = reconstruction.esti_color(kept_rgba.astype(np.uint16), xyz.cuda()).astype(np.uint8)
+    assert np.array_equal(got, want[2])
+    assert (got != kept_rgba).any(1).sum() > 100                                  # the back half was recoloured
+    # the rewritten file holds exactly the kept component
+    v1, c1, f1 = reconstruction.read_obj_with_color(base)
+    assert np.array_equal(f1, kept_f) and np.allclose(v1, kept_v, atol=5e-5)
+    # only open components: the reference's cc[0] raises IndexError
+    only_sheet = str(tmp_path / 'sheet.obj')
+    v, f = mesh_util.marching_cubes_device(_Ctx('cuda'), torch.from_numpy((0.5 + 5 * sheet).astype(np.float32)).cuda(), 0.5)
+    mesh_util.save_obj_mesh_with_color(only_sheet, v.cpu().numpy().astype(np.float64), f.cpu().numpy(), np.zeros((len(v), 3)))
+    with pytest.raises(IndexError):
+        reconstruction.meshcleaning(only_sheet, 'cuda')
+
+
+def test_gen_mesh_imgcolor_plus(tmp_path, capsys):
+    """`gen_mesh_imgColor_plus` (`reconstruction.py:127-178`) end to end on the network's own mesh: the result - a cleaned,
+    recoloured mesh or, exactly like the reference, a printed error when the widest watertight component has no silhouette
+    vertex - must be what the oracle pipeline gives on the same image-coloured OBJ."""
     from pifuhd_amd import nets, reconstruction, synth
     sd, oc, of = golden_nets()
     of.loadSizeBig = 128
@@ -247,38 +316,16 @@ def test_gen_mesh_imgcolor_plus(tmp_path, capsys):
     synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
     base = str(tmp_path / 'base.obj')
     assert reconstruction.gen_mesh_imgColor(64, netMR, 'cuda', data, base) is not None
+    want = _plus_oracle(base, data['calib'])
     path = str(tmp_path / 'plus.obj')
+    capsys.readouterr()
     out = reconstruction.gen_mesh_imgColor_plus(64, netMR, 'cuda', data, path)
     shown = capsys.readouterr().out
-    if out is None:
-        # the synthetic surface may have no watertight component: then the reference's cc[0] raises and 'error' is printed
-        assert 'error' in shown
-        v0, c0, f0 = reconstruction.read_obj_with_color(base)
-        _, open_face = O.face_components(f0)
-        lab, _ = O.face_components(f0)
-        assert all(open_face[lab == r].any() for r in np.unique(lab))
+    assert 'Processing mesh cleaning' in shown
+    if isinstance(want, Exception):
+        assert out is None and 'error' in shown
         return
     verts, faces, rgba = out
-    assert 'Processing mesh cleaning' in shown
-    # stage 1: the component choice, from the file gen_mesh_imgColor wrote
-    v0, c0, f0 = reconstruction.read_obj_with_color(base)
-    lab, open_face = O.face_components(f0)
-    best, best_ext = None, None
-    for r in np.unique(lab):
-        sel = lab == r
-        if open_face[sel].any():
-            continue
-        ext = np.ptp(v0[:, 0][f0[sel]])
-        if best is None or best_ext < ext:
-            best, best_ext = r, ext
-    used = np.unique(f0[lab == best])
-    assert np.array_equal(verts, v0[used])
-    remap = np.full(len(v0), -1); remap[used] = np.arange(len(used))
-    assert np.array_equal(faces, remap[f0[lab == best]])
-    # stage 2: colours = uint8(round(255 c)) recoloured by esti_color on the projected vertices
-    rgba0 = np.concatenate([np.clip(np.rint(c0[used] * 255.0), 0, 255), np.full((len(used), 1), 255.0)], 1).astype(np.uint16)
-    xyz = O.orthogonal(torch.from_numpy(verts.T).float()[None], data['calib'])[0].numpy().T
-    assert np.array_equal(rgba, O.esti_color(rgba0, xyz).astype(np.uint8))
-    # the file holds the cleaned mesh with colours / 255 and the faces in their file order
+    assert np.array_equal(verts, want[0]) and np.array_equal(faces, want[1]) and np.array_equal(rgba, want[2])
     v1, c1, f1 = reconstruction.read_obj_with_color(path)
     assert np.array_equal(f1, faces) and np.allclose(v1, verts, atol=5e-5) and np.allclose(c1, rgba[:, :3] / 255.0, atol=5e-5)
