@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 os.makedirs('profiles', exist_ok=True)
 
 
@@ -20,6 +20,10 @@ def short(name):
     return name.split('<')[0][:60] if name.startswith('k_') else name[:60]
 
 
+def is_col(name):
+    return 'k_sample_col' in name
+
+
 # (1) kernel stats
 stats = sorted(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime, reverse=True)
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
@@ -27,7 +31,7 @@ with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 '
             '--no-cpu-baseline --no-genmesh   (MI355X, 1 GPU)\n')
     f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
-    for r in rows[:12]:
+    for r in rows[:16]:
         f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 
 
@@ -40,11 +44,12 @@ def pmc(dirname):
 
 
 fetch, write, sq = pmc('pmc_fetch'), pmc('pmc_write'), pmc('pmc_sq')
+fetch_c, write_c = pmc('pmc_fetch_canon'), pmc('pmc_write_canon')      # passes with the canonical per-point pass on
 summary = {}
 GEMM = next((k for k in ('k_mlp_gemm_tri', 'k_mlp_gemm_buf') if k in fetch), 'k_mlp_gemm')
-for k in (GEMM, 'k_walk', 'k_sample_col', 'k_seg_prepare', 'k_last_layer'):
-    f = fetch.get(k, {}).get('FETCH_SIZE', [])
-    w = write.get(k, {}).get('WRITE_SIZE', [])
+for k in (GEMM, 'k_walk', 'k_sample', 'k_sample_col', 'k_seg_prepare', 'k_last_layer'):
+    f = (fetch_c if k == 'k_sample' else fetch).get(k, {}).get('FETCH_SIZE', [])
+    w = (write_c if k == 'k_sample' else write).get(k, {}).get('WRITE_SIZE', [])
     if k != GEMM and f and w:      # small set-up launches would dilute the per-launch figure of the batch-sized ones
         f = [x for x in f if x > 0.5 * max(f)]
         w = [x for x in w if x > 0.5 * max(w)]
@@ -65,5 +70,7 @@ json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py
                      'geometry: per-launch averages over the same launch mix as the timed run)',
            'gemm_kernel': GEMM,
            'k_mlp_gemm_hbm_bytes_per_launch': summary.get(GEMM, {}).get('hbm_bytes_per_launch'),
+           # per-point sampler of the canonical pass (the batch-sized launches only)
+           'k_sample_hbm_bytes_per_launch': summary.get('k_sample', {}).get('hbm_bytes_per_launch'),
            'detail': summary}, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(summary, indent=1))
