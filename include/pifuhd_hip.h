@@ -165,6 +165,25 @@ int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
                   int64_t *nverts, int64_t *nfaces, pifu_stream stream);
 int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream);
 
+/* ---- the same marching cubes over axis-0 slabs of one volume (one slab per GPU; SURVEY 8e, BASELINE config 5) ----
+ * skimage scans cells with axis 0 outermost (mesh_util.py:84), so the cells [z_first, z_first + n0 - 1) of a slab own one
+ * contiguous range of the mesh's vertex and face numbers.  A slab is the n0 >= 2 node planes [z_first, z_first + n0) of the
+ * volume (neighbouring slabs share one node plane).  Per slab, in this order:
+ *   pifu_mc_slab_count  - vertices / faces this slab's cells create (a cell creates the vertex of an edge iff it is the first
+ *                         cell of the WHOLE volume touching it) and the slab's value range; synchronises.  The caller sums
+ *                         the counts (vert_base = vertices of all lower slabs), reduces the range over the slabs and raises
+ *                         skimage's two errors itself (level outside the range; no vertex at all);
+ *   pifu_mc_slab_verts  - verts fp32 [nverts][3] of this slab (coordinates of the whole volume) and, in halo_out (device
+ *                         int32 [2][n1][n2], may be NULL for the top slab), the mesh-wide numbers of the vertices on the x- /
+ *                         y-edges of the slab's top node plane;
+ *   pifu_mc_slab_faces  - faces int32 [nfaces][3] in mesh-wide vertex numbers; halo_in = the halo_out of the slab below
+ *                         (NULL iff z_first == 0).
+ * Concatenating the slabs' arrays in slab order gives pifu_mc_emit's output bit for bit. */
+int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, int n0, int n1, int n2, int z_first, double level,
+                       int64_t *nverts, int64_t *nfaces, float *vmin, float *vmax, pifu_stream stream);
+int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base, int32_t *halo_out, pifu_stream stream);
+int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pifu_stream stream);
+
 /* ---- per-vertex normals: PIFuMRNet.calc_normal (PIFuMRNet.py:188-243) as used by gen_mesh -------- */
 /* verts: device fp32 [3][n]; every call is ONE GroupNorm batch of 4n points (p, p+dx, p+dy, p+dz
  * interleaved per point); normals: device fp32 [3][n] unit normals; pred4 (device fp32 [4n], may be NULL) receives the

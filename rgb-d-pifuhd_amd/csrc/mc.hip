@@ -184,6 +184,9 @@ struct Vol {
     // 8 x 8 x 8-cell bricks whose 9 x 9 x 9 nodes are not all on one side of the level (k_mc_bricks); null = classify every cell
     const uint8_t *brick;
     int b0, b1, b2;
+    // slab mode (pifu_mc_slab_*): the volume holds node planes [zoff, zoff + n0) of a taller one.  Vertex ownership along
+    // axis 0 and the axis-0 coordinate of the vertices refer to the tall volume; 0 for a whole volume
+    int zoff;
 };
 
 __device__ __forceinline__ double vol_at(const Vol &v, int z, int y, int x)
@@ -222,7 +225,7 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
     ci.row = nullptr;
     if (index == 0 || index == 255) return false;
     ci.nt = choose_tiling(ci.c, index, &ci.row);
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z == 0 ? 4 : 0);
+    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
     unsigned seen = 0;
     for (int k = 0; k < 3 * ci.nt; ++k) {
         const int e = ci.row[k];
@@ -314,7 +317,7 @@ __device__ __forceinline__ size_t edge_slot(const Vol &v, int axis, int z, int y
 }
 
 // pass 2: vertex positions + per-grid-edge vertex index volume
-__global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, float *verts, int32_t *edge_index)
+__global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, int64_t vert_base, float *verts, int32_t *edge_index)
 {
     __shared__ uint32_t sh[4];
     const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -324,8 +327,9 @@ __global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, float *verts,
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan_256(active ? (uint32_t)ci.nown : 0u, sh, &tot);
     if (!active || ci.nown == 0) return;
+    // `verts` is this volume's own array (local numbering); the index volume holds numbers of the whole mesh
     int64_t vid = (int64_t)blk_verts[blockIdx.x] + pre;
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z == 0 ? 4 : 0);
+    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
     unsigned seen = 0;
     for (int k = 0; k < 3 * ci.nt; ++k) {
         const int e = ci.row[k];
@@ -341,7 +345,7 @@ __global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, float *verts,
                 sz = __dadd_rn(sz, __dmul_rn(w, (double)COFF[i][2]));
                 sw = __dadd_rn(sw, w);
             }
-            verts[3 * vid + 0] = (float)__dadd_rn((double)ci.z, sz / sw);
+            verts[3 * vid + 0] = (float)__dadd_rn((double)(ci.z + v.zoff), sz / sw);
             verts[3 * vid + 1] = (float)__dadd_rn((double)ci.y, sy / sw);
             verts[3 * vid + 2] = (float)__dadd_rn((double)ci.x, sx / sw);
             ++vid;
@@ -354,18 +358,19 @@ __global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, float *verts,
             const double clo = a_is_lo ? ci.c[ca] : ci.c[cb], chi = a_is_lo ? ci.c[cb] : ci.c[ca];
             const double wlo = 1.0 / __dadd_rn(MC_EPS, fabs(clo)), whi = 1.0 / __dadd_rn(MC_EPS, fabs(chi));
             const double t = whi / __dadd_rn(wlo, whi);
-            verts[3 * vid + 0] = (float)(axis == 2 ? __dadd_rn((double)bz, t) : (double)bz);
+            const int gz = bz + v.zoff;
+            verts[3 * vid + 0] = (float)(axis == 2 ? __dadd_rn((double)gz, t) : (double)gz);
             verts[3 * vid + 1] = (float)(axis == 1 ? __dadd_rn((double)by, t) : (double)by);
             verts[3 * vid + 2] = (float)(axis == 0 ? __dadd_rn((double)bx, t) : (double)bx);
-            edge_index[edge_slot(v, axis, bz, by, bx)] = (int32_t)vid;
+            edge_index[edge_slot(v, axis, bz, by, bx)] = (int32_t)(vert_base + vid);
             ++vid;
         }
     }
 }
 
 // pass 3: triangle indices ('descent' => the three indices of every triangle are reversed)
-__global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_t *blk_tris, const int32_t *edge_index,
-                           int32_t *faces)
+__global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_t *blk_tris, int64_t vert_base,
+                           const int32_t *edge_index, int32_t *faces)
 {
     __shared__ uint32_t sh[4];
     const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -375,10 +380,10 @@ __global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan_256(active ? ((uint32_t)ci.nown | ((uint32_t)ci.nt << 16)) : 0u, sh, &tot);
     if (!active) return;
-    const int64_t vbase = (int64_t)blk_verts[blockIdx.x] + (pre & 0xffffu);
+    const int64_t vbase = vert_base + (int64_t)blk_verts[blockIdx.x] + (pre & 0xffffu);
     int64_t f = (int64_t)blk_tris[blockIdx.x] + (pre >> 16);
     // index of the centre vertex = vbase + number of owned vertices first referenced before it
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z == 0 ? 4 : 0);
+    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
     int32_t centre = -1;
     {
         unsigned seen = 0;
@@ -407,6 +412,117 @@ __global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_
     }
 }
 
+struct McArena {
+    uint64_t *blk_verts, *blk_tris, *totals;
+    float *mm;
+    uint8_t *brick;
+    int32_t *edge_index;
+    int64_t nblocks, nbricks;
+    size_t bytes;
+};
+
+constexpr int MM_BLOCKS = 1024;
+
+// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][brick map][edge_index 3*N int32]
+McArena carve(const Vol &v, char *base)
+{
+    McArena a;
+    a.nblocks = (v.ncells + 255) / 256;
+    a.nbricks = (int64_t)v.b0 * v.b1 * v.b2;
+    const size_t scan_bytes = (size_t)round_up((a.nblocks + 1) * 8, 256);
+    const size_t mm_bytes = (size_t)round_up((2 * MM_BLOCKS + 2) * 4, 256);
+    const size_t brick_bytes = (size_t)round_up(a.nbricks, 256);
+    const size_t edge_bytes = (size_t)3 * v.n0 * v.n1 * v.n2 * sizeof(int32_t);
+    a.blk_verts = (uint64_t *)base;
+    a.blk_tris = (uint64_t *)(base + scan_bytes);
+    a.totals = (uint64_t *)(base + 2 * scan_bytes);
+    a.mm = (float *)(base + 2 * scan_bytes + 256);
+    a.brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + brick_bytes);
+    a.bytes = 2 * scan_bytes + 256 + mm_bytes + brick_bytes + edge_bytes;
+    return a;
+}
+
+Vol make_vol(const void *volume, int dtype, int n0, int n1, int n2, double level, int zoff)
+{
+    return Vol{volume, dtype, n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1), level, nullptr,
+               (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8, zoff};
+}
+
+// counting half, shared by the whole-volume and the slab entry points: totals and the value range on the host
+int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level, int zoff,
+                  uint64_t *nv, uint64_t *nf, float *lo, float *hi, hipStream_t st)
+{
+    PIFU_HIP(hipSetDevice(ctx->device));
+    ctx->mc.valid = false;
+    Vol v = make_vol(volume, dtype, n0, n1, n2, level, zoff);
+    McArena a = carve(v, nullptr);
+    int rc = pifu_ensure(ctx->mc_arena, a.bytes);
+    if (rc) return rc;
+    a = carve(v, (char *)ctx->mc_arena.p);
+    hipEvent_t prof_stop;
+    rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mc_bricks, dim3((unsigned)((a.nbricks + 3) / 4)), dim3(256), 0, st, v, a.brick);
+    v.brick = a.brick;
+    hipLaunchKernelGGL(k_mc_minmax, dim3(MM_BLOCKS), dim3(256), 0, st, v, a.mm + 2);
+    hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), MM_BLOCKS, a.mm);
+    hipLaunchKernelGGL(k_mc_count, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, a.blk_verts, a.blk_tris);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, a.blk_verts, a.nblocks, a.totals);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, a.blk_tris, a.nblocks, a.totals + 1);
+    // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
+    rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
+    if (rc) return rc;
+    char *pin = (char *)ctx->pinned;
+    PIFU_HIP(hipMemcpyAsync(pin, a.totals, 16, hipMemcpyDeviceToHost, st));
+    PIFU_HIP(hipMemcpyAsync(pin + 16, a.mm, 8, hipMemcpyDeviceToHost, st));
+    PIFU_HIP(hipStreamSynchronize(st));
+    *nv = ((uint64_t *)pin)[0];
+    *nf = ((uint64_t *)pin)[1];
+    *lo = ((float *)(pin + 16))[0];
+    *hi = ((float *)(pin + 16))[1];
+    McState &m = ctx->mc;
+    m.n0 = n0; m.n1 = n1; m.n2 = n2;
+    m.level = level; m.dtype = dtype; m.volume = volume; m.zoff = zoff;
+    m.nverts = (int64_t)*nv; m.nfaces = (int64_t)*nf;
+    m.verts_done = false;
+    m.vert_base = 0;
+    return PIFU_OK;
+}
+
+int mc_verts_impl(pifu_ctx *ctx, float *verts, int64_t vert_base, hipStream_t st)
+{
+    McState &m = ctx->mc;
+    Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p);
+    v.brick = a.brick;                                                        // built by the counting half for this volume
+    hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, (const uint64_t *)a.blk_verts, vert_base,
+                       verts, a.edge_index);
+    m.verts_done = true;
+    m.vert_base = vert_base;
+    return PIFU_OK;
+}
+
+int mc_faces_impl(pifu_ctx *ctx, int32_t *faces, hipStream_t st)
+{
+    McState &m = ctx->mc;
+    Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p);
+    v.brick = a.brick;
+    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, (const uint64_t *)a.blk_verts,
+                       (const uint64_t *)a.blk_tris, m.vert_base, (const int32_t *)a.edge_index, faces);
+    return PIFU_OK;
+}
+
+// the x- and y-edge index planes of node plane z of the current volume: [2][n1][n2] int32
+int32_t *edge_plane(pifu_ctx *ctx, int axis, int z)
+{
+    const McState &m = ctx->mc;
+    Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p);
+    return a.edge_index + (size_t)axis * m.n0 * m.n1 * m.n2 + (size_t)z * m.n1 * m.n2;
+}
+
 }  // namespace
 
 extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level,
@@ -415,47 +531,10 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     PIFU_REQUIRE(ctx && volume && nverts && nfaces, PIFU_ERR_INVALID, "pifu_mc_count: null argument");
     PIFU_REQUIRE(dtype == 0 || dtype == 1, PIFU_ERR_INVALID, "pifu_mc_count: dtype must be 0 (f32) or 1 (f64)");
     PIFU_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, PIFU_ERR_INVALID, "Input array must be at least 2x2x2.");
-    PIFU_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    ctx->mc.valid = false;
-    Vol v{volume, dtype, n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1), level, nullptr,
-          (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8};
-    const int64_t nblocks = (v.ncells + 255) / 256;
-    const int mm_blocks = 1024;
-    // arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][brick map][edge_index 3*N int32]
-    const size_t scan_bytes = (size_t)round_up((nblocks + 1) * 8, 256);
-    const size_t mm_bytes = (size_t)round_up((2 * mm_blocks + 2) * 4, 256);
-    const int64_t nbricks = (int64_t)v.b0 * v.b1 * v.b2;
-    const size_t brick_bytes = (size_t)round_up(nbricks, 256);
-    const size_t edge_bytes = (size_t)3 * n0 * n1 * n2 * sizeof(int32_t);
-    int rc = pifu_ensure(ctx->mc_arena, 2 * scan_bytes + 256 + mm_bytes + brick_bytes + edge_bytes);
+    uint64_t nv, nf;
+    float lo, hi;
+    int rc = mc_count_impl(ctx, volume, dtype, n0, n1, n2, level, 0, &nv, &nf, &lo, &hi, (hipStream_t)stream);
     if (rc) return rc;
-    char *base = (char *)ctx->mc_arena.p;
-    uint64_t *blk_verts = (uint64_t *)base;
-    uint64_t *blk_tris = (uint64_t *)(base + scan_bytes);
-    uint64_t *totals = (uint64_t *)(base + 2 * scan_bytes);
-    float *mm = (float *)(base + 2 * scan_bytes + 256);
-    uint8_t *brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
-    hipEvent_t prof_stop;
-    rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_mc_bricks, dim3((unsigned)((nbricks + 3) / 4)), dim3(256), 0, st, v, brick);
-    v.brick = brick;
-
-    hipLaunchKernelGGL(k_mc_minmax, dim3(mm_blocks), dim3(256), 0, st, v, mm + 2);
-    hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(mm + 2), mm_blocks, mm);
-    hipLaunchKernelGGL(k_mc_count, dim3((unsigned)nblocks), dim3(256), 0, st, v, blk_verts, blk_tris);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, blk_verts, nblocks, totals);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, blk_tris, nblocks, totals + 1);
-    // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
-    rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
-    if (rc) return rc;
-    char *pin = (char *)ctx->pinned;
-    PIFU_HIP(hipMemcpyAsync(pin, totals, 16, hipMemcpyDeviceToHost, st));
-    PIFU_HIP(hipMemcpyAsync(pin + 16, mm, 8, hipMemcpyDeviceToHost, st));
-    PIFU_HIP(hipStreamSynchronize(st));
-    const uint64_t nv = ((uint64_t *)pin)[0], nf = ((uint64_t *)pin)[1];
-    const float lo = ((float *)(pin + 16))[0], hi = ((float *)(pin + 16))[1];
     if (level < (double)lo || level > (double)hi) {
         pifu_set_error("Surface level must be within volume data range.");
         return PIFU_ERR_MC_LEVEL;
@@ -466,9 +545,7 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     }
     PIFU_REQUIRE(nv < ((uint64_t)1 << 31), PIFU_ERR_INVALID, "pifu_mc_count: %llu vertices do not fit int32 face indices", (unsigned long long)nv);
     ctx->mc.valid = true;
-    ctx->mc.n0 = n0; ctx->mc.n1 = n1; ctx->mc.n2 = n2;
-    ctx->mc.level = level; ctx->mc.dtype = dtype; ctx->mc.volume = volume;
-    ctx->mc.nverts = (int64_t)nv; ctx->mc.nfaces = (int64_t)nf;
+    ctx->mc.slab = false;
     *nverts = (int64_t)nv;
     *nfaces = (int64_t)nf;
     return PIFU_OK;
@@ -477,30 +554,81 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
 extern "C" int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && verts && faces, PIFU_ERR_INVALID, "pifu_mc_emit: null argument");
-    PIFU_REQUIRE(ctx->mc.valid, PIFU_ERR_STATE, "pifu_mc_emit: call pifu_mc_count first");
+    PIFU_REQUIRE(ctx->mc.valid && !ctx->mc.slab, PIFU_ERR_STATE, "pifu_mc_emit: call pifu_mc_count first");
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const McState &m = ctx->mc;
-    Vol v{m.volume, m.dtype, m.n0, m.n1, m.n2, m.n0 - 1, m.n1 - 1, m.n2 - 1, (int64_t)(m.n0 - 1) * (m.n1 - 1) * (m.n2 - 1), m.level,
-          nullptr, (m.n0 - 1 + 7) / 8, (m.n1 - 1 + 7) / 8, (m.n2 - 1 + 7) / 8};
-    const int64_t nblocks = (v.ncells + 255) / 256;
-    const size_t scan_bytes = (size_t)round_up((nblocks + 1) * 8, 256);
-    const size_t mm_bytes = (size_t)round_up((2 * 1024 + 2) * 4, 256);
-    const size_t brick_bytes = (size_t)round_up((int64_t)v.b0 * v.b1 * v.b2, 256);
-    char *base = (char *)ctx->mc_arena.p;
-    uint64_t *blk_verts = (uint64_t *)base;
-    uint64_t *blk_tris = (uint64_t *)(base + scan_bytes);
-    v.brick = (const uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);      // built by pifu_mc_count for this volume
-    int32_t *edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + brick_bytes);
     hipEvent_t prof_stop;
     int rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts, verts, edge_index);
-    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)nblocks), dim3(256), 0, st, v, (const uint64_t *)blk_verts,
-                       (const uint64_t *)blk_tris, (const int32_t *)edge_index, faces);
+    mc_verts_impl(ctx, verts, 0, st);
+    mc_faces_impl(ctx, faces, st);
     // timed: the emit half; work = the vertex and face streams written (12 B each)
     rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, 12.0 * ((double)m.nverts + (double)m.nfaces), st);
     if (rc) return rc;
+    PIFU_HIP(hipGetLastError());
+    ctx->mc.valid = false;
+    return PIFU_OK;
+}
+
+// ---- slab-sharded marching cubes (axis-0 slabs with a one-plane halo + exclusive prefix of the counts) ----------
+extern "C" int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, int n0, int n1, int n2, int z_first, double level,
+                                  int64_t *nverts, int64_t *nfaces, float *vmin, float *vmax, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && slab && nverts && nfaces && vmin && vmax, PIFU_ERR_INVALID, "pifu_mc_slab_count: null argument");
+    PIFU_REQUIRE(dtype == 0 || dtype == 1, PIFU_ERR_INVALID, "pifu_mc_slab_count: dtype must be 0 (f32) or 1 (f64)");
+    PIFU_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2 && z_first >= 0, PIFU_ERR_INVALID,
+                 "pifu_mc_slab_count: a slab needs at least 2 node planes of at least 2x2 nodes (got %d x %d x %d at plane %d)", n0, n1,
+                 n2, z_first);
+    uint64_t nv, nf;
+    int rc = mc_count_impl(ctx, slab, dtype, n0, n1, n2, level, z_first, &nv, &nf, vmin, vmax, (hipStream_t)stream);
+    if (rc) return rc;
+    ctx->mc.valid = true;
+    ctx->mc.slab = true;
+    *nverts = (int64_t)nv;
+    *nfaces = (int64_t)nf;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base, int32_t *halo_out, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_mc_slab_verts: null context");
+    PIFU_REQUIRE(ctx->mc.valid && ctx->mc.slab, PIFU_ERR_STATE, "pifu_mc_slab_verts: call pifu_mc_slab_count first");
+    const McState &m = ctx->mc;
+    PIFU_REQUIRE(verts || m.nverts == 0, PIFU_ERR_INVALID, "pifu_mc_slab_verts: null vertex array for %lld vertices", (long long)m.nverts);
+    PIFU_REQUIRE(vert_base >= 0 && vert_base + m.nverts < ((int64_t)1 << 31), PIFU_ERR_INVALID,
+                 "pifu_mc_slab_verts: vertex numbers %lld + %lld do not fit int32 face indices", (long long)vert_base, (long long)m.nverts);
+    PIFU_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    mc_verts_impl(ctx, verts, vert_base, st);
+    if (halo_out) {
+        // the vertices on the x / y edges of the slab's top node plane, by their numbers in the whole mesh: the slab above
+        // references them from its bottom cells.  Slots of edges without a vertex hold stale values no cell ever reads.
+        const size_t plane = (size_t)m.n1 * m.n2 * sizeof(int32_t);
+        PIFU_HIP(hipMemcpyAsync(halo_out, edge_plane(ctx, 0, m.n0 - 1), plane, hipMemcpyDeviceToDevice, st));
+        PIFU_HIP(hipMemcpyAsync((char *)halo_out + plane, edge_plane(ctx, 1, m.n0 - 1), plane, hipMemcpyDeviceToDevice, st));
+    }
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+extern "C" int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_mc_slab_faces: null context");
+    PIFU_REQUIRE(ctx->mc.valid && ctx->mc.slab && ctx->mc.verts_done, PIFU_ERR_STATE,
+                 "pifu_mc_slab_faces: call pifu_mc_slab_count and pifu_mc_slab_verts first");
+    const McState &m = ctx->mc;
+    PIFU_REQUIRE(faces || m.nfaces == 0, PIFU_ERR_INVALID, "pifu_mc_slab_faces: null face array for %lld faces", (long long)m.nfaces);
+    PIFU_REQUIRE((m.zoff == 0) == (halo_in == nullptr), PIFU_ERR_INVALID,
+                 "pifu_mc_slab_faces: the slab starting at node plane %d %s a halo", m.zoff, m.zoff ? "needs" : "must not be given");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (halo_in) {
+        const size_t plane = (size_t)m.n1 * m.n2 * sizeof(int32_t);
+        PIFU_HIP(hipMemcpyAsync(edge_plane(ctx, 0, 0), halo_in, plane, hipMemcpyDeviceToDevice, st));
+        PIFU_HIP(hipMemcpyAsync(edge_plane(ctx, 1, 0), (const char *)halo_in + plane, plane, hipMemcpyDeviceToDevice, st));
+    }
+    mc_faces_impl(ctx, faces, st);
     PIFU_HIP(hipGetLastError());
     ctx->mc.valid = false;
     return PIFU_OK;

@@ -93,6 +93,10 @@ struct McState {
     int dtype = 0;
     const void *volume = nullptr;
     int64_t nverts = 0, nfaces = 0;
+    // slab mode (pifu_mc_slab_*): first node plane of the slab in the tall volume, numbering offset of its vertices
+    bool slab = false, verts_done = false;
+    int zoff = 0;
+    int64_t vert_base = 0;
 };
 
 struct pifu_ctx {

@@ -188,3 +188,62 @@ def gather_runs(runs, mine, run_fn, width, device, group=None):
     for rk, (l, r) in enumerate(runs):          # ranks with work are the first len(runs) ranks (shard_range is monotone)
         out[l:r] = full[rk * slot_rows: rk * slot_rows + (r - l)]
     return out
+
+
+# `reconstruction(..., sharded=True)` runs marching cubes over one axis-0 slab per rank from this resolution on (below it
+# the replicated run is a few milliseconds and cheaper than the three exchanges of the slab form)
+SLAB_MC_MIN_RESOLUTION = 1024
+
+
+def marching_cubes_sharded(ctx, volume, level, group=None):
+    """Lewiner marching cubes of a replicated device volume with ONE axis-0 slab per rank (the serial scan of
+    `marching_cubes_lewiner`, `mesh_util.py:84`, has axis 0 outermost, so a slab owns a contiguous range of the mesh's
+    vertex and face numbers).  Exchanges: the per-slab counts and value ranges (exclusive prefix = numbering offset, and
+    scikit-image's two exceptions, raised on every rank alike), the vertex numbers on each slab's top node plane
+    (int32 [2][n1][n2], read by the slab above), and the finished vertex / face arrays.  Returns (verts float32 [V, 3],
+    faces int32 [F, 3]) on the device, identical on every rank and bit-identical to `mesh_util.marching_cubes_device`."""
+    import torch.distributed as dist
+    from . import _lib
+    from .mesh_util import SlabMarchingCubes, check_mc_range, marching_cubes_device, slab_planes
+    if not collective_active():
+        return marching_cubes_device(ctx, volume, level)
+    rank, ws = world()
+    vol = volume.contiguous()
+    if vol.dim() != 3 or min(vol.shape) < 2:
+        raise ValueError('Input array must be at least 2x2x2.')
+    dev = vol.device
+    n1, n2 = vol.shape[1], vol.shape[2]
+    mine = slab_planes(vol.shape[0], ws)[rank]
+    step = SlabMarchingCubes(ctx, vol, level, *mine) if mine is not None else None
+    nv, nf, lo, hi = step.count() if step else (0, 0, float('inf'), float('-inf'))
+    # float64 carries the counts exactly (< 2^31 vertices by the int32 face indices) next to the range
+    stat = torch.tensor([nv, nf, lo, hi], device=dev, dtype=torch.float64)
+    stats = torch.empty(ws * 4, device=dev, dtype=torch.float64)      # gathered tensors are concatenated along axis 0
+    dist.all_gather_into_tensor(stats, stat, group=group)
+    stats = stats.view(ws, 4).cpu()
+    nvs = [int(x) for x in stats[:, 0]]
+    nfs = [int(x) for x in stats[:, 1]]
+    check_mc_range(float(level), float(stats[:, 2].min()), float(stats[:, 3].max()), sum(nvs))
+    if sum(nvs) >= 2 ** 31:
+        raise _lib.PifuError(_lib.ERR_INVALID, 'marching_cubes_sharded: %d vertices do not fit int32 face indices' % sum(nvs))
+    if step:
+        verts, halo = step.verts(sum(nvs[:rank]))
+    else:
+        verts = torch.empty(0, 3, device=dev, dtype=torch.float32)
+        halo = torch.zeros(2, n1, n2, device=dev, dtype=torch.int32)
+    halos = torch.empty(ws * 2, n1, n2, device=dev, dtype=torch.int32)
+    dist.all_gather_into_tensor(halos, halo, group=group)
+    halos = halos.view(ws, 2, n1, n2)
+    # slabs without cells are the last ranks (slab_planes deals the cell layers out from rank 0), so the slab below is rank - 1
+    faces = step.faces(halos[rank - 1] if rank > 0 else None) if step else torch.empty(0, 3, device=dev, dtype=torch.int32)
+    cap_v, cap_f = max(max(nvs), 1), max(max(nfs), 1)
+    pad_v = torch.zeros(cap_v, 3, device=dev, dtype=torch.float32)
+    pad_v[:nv] = verts
+    pad_f = torch.zeros(cap_f, 3, device=dev, dtype=torch.int32)
+    pad_f[:nf] = faces
+    all_v = torch.empty(ws * cap_v, 3, device=dev, dtype=torch.float32)
+    all_f = torch.empty(ws * cap_f, 3, device=dev, dtype=torch.int32)
+    dist.all_gather_into_tensor(all_v, pad_v, group=group)
+    dist.all_gather_into_tensor(all_f, pad_f, group=group)
+    all_v, all_f = all_v.view(ws, cap_v, 3), all_f.view(ws, cap_f, 3)
+    return (torch.cat([all_v[r, :nvs[r]] for r in range(ws)]), torch.cat([all_f[r, :nfs[r]] for r in range(ws)]))

@@ -93,13 +93,93 @@ def marching_cubes_device(ctx, volume, level):
     return verts, faces
 
 
+def slab_planes(n0, nslabs):
+    """Axis-0 slabs of a volume with `n0` node planes: the n0 - 1 cell layers are dealt out in contiguous, near-equal
+    runs; returns one (z_first, n_planes) per slab (neighbours share a node plane), None for slabs left without cells."""
+    cells = n0 - 1
+    per = (cells + nslabs - 1) // nslabs
+    out = []
+    for k in range(nslabs):
+        c0 = min(k * per, cells)
+        c1 = min(c0 + per, cells)
+        out.append((c0, c1 - c0 + 1) if c1 > c0 else None)
+    return out
+
+
+class SlabMarchingCubes:
+    """The three steps of marching cubes on ONE axis-0 slab of a device volume (`pifu_mc_slab_*`); the caller supplies
+    what crosses slabs: the vertex-number offset and the halo plane of the slab below."""
+
+    def __init__(self, ctx, volume, level, z_first, n_planes):
+        if volume.dim() != 3 or min(volume.shape[1:]) < 2 or n_planes < 2:
+            raise ValueError('Input array must be at least 2x2x2.')
+        self.ctx, self.level, self.z_first = ctx, float(level), int(z_first)
+        self.slab = volume[z_first:z_first + n_planes]              # a view: axis 0 is the slowest axis
+        assert self.slab.is_contiguous()
+        self.dtype = {torch.float32: 0, torch.float64: 1}[volume.dtype]
+        self.nv = self.nf = 0
+
+    def count(self):
+        nv, nf, lo, hi = C.c_int64(0), C.c_int64(0), C.c_float(0), C.c_float(0)
+        v = self.slab
+        _lib.call('pifu_mc_slab_count', self.ctx.h, _ptr(v), self.dtype, v.shape[0], v.shape[1], v.shape[2], self.z_first,
+                  self.level, C.byref(nv), C.byref(nf), C.byref(lo), C.byref(hi), _stream_ptr(self.ctx.device))
+        self.nv, self.nf = nv.value, nf.value
+        return self.nv, self.nf, lo.value, hi.value
+
+    def verts(self, vert_base, want_halo=True):
+        dev = self.ctx.device
+        verts = torch.empty(self.nv, 3, device=dev, dtype=torch.float32)
+        halo = torch.zeros(2, self.slab.shape[1], self.slab.shape[2], device=dev, dtype=torch.int32) if want_halo else None
+        _lib.call('pifu_mc_slab_verts', self.ctx.h, _ptr(verts) if self.nv else None, int(vert_base),
+                  _ptr(halo) if want_halo else None, _stream_ptr(dev))
+        return verts, halo
+
+    def faces(self, halo_in):
+        dev = self.ctx.device
+        faces = torch.empty(self.nf, 3, device=dev, dtype=torch.int32)
+        _lib.call('pifu_mc_slab_faces', self.ctx.h, _ptr(faces) if self.nf else None,
+                  _ptr(halo_in) if halo_in is not None else None, _stream_ptr(dev))
+        return faces
+
+
+def check_mc_range(level, lo, hi, nverts):
+    """The two exceptions scikit-image raises (`mesh_util.py:84` -> marching_cubes_lewiner), from totals over all slabs."""
+    if level < lo or level > hi:
+        raise ValueError('Surface level must be within volume data range.')
+    if nverts == 0:
+        raise RuntimeError('No surface found at the given iso value.')
+
+
+def marching_cubes_slabs(ctx, volume, level, nslabs):
+    """`marching_cubes_device` computed slab by slab in one process (what `dist.marching_cubes_sharded` does with one slab
+    per rank): same vertices and faces, bit for bit; the working set is that of one slab."""
+    vol = volume.contiguous()
+    if vol.dim() != 3 or min(vol.shape) < 2:
+        raise ValueError('Input array must be at least 2x2x2.')
+    runs = [r for r in slab_planes(vol.shape[0], nslabs) if r is not None]
+    verts, faces, halo, base = [], [], None, 0
+    lo, hi = float('inf'), float('-inf')
+    for (z_first, n_planes) in runs:
+        step = SlabMarchingCubes(ctx, vol, level, z_first, n_planes)
+        nv, _, l, h = step.count()
+        lo, hi = min(lo, l), max(hi, h)
+        v, halo_out = step.verts(base)
+        faces.append(step.faces(halo))
+        verts.append(v)
+        halo, base = halo_out, base + nv
+    check_mc_range(float(level), lo, hi, base)
+    return torch.cat(verts), torch.cat(faces)
+
+
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
                    num_samples=10000, transform=None, return_sdf=False, sharded=False):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
     values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
     [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty.
     `sharded=True`: the grid evaluation is split over the ranks of the initialised process group
-    (`pifuhd_amd.dist`); every rank gets the identical field and runs marching cubes redundantly."""
+    (`pifuhd_amd.dist`); every rank gets the identical field; marching cubes runs redundantly on it, or - from
+    `dist.SLAB_MC_MIN_RESOLUTION` on - one axis-0 slab per rank (`dist.marching_cubes_sharded`), with the same result."""
     ctx = _ctx_of(net)
     from . import dist as pdist
     if sharded and pdist.collective_active():
@@ -112,7 +192,10 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     else:
         sdf, _ = eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree)
     try:
-        verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
+        if sharded and pdist.collective_active() and int(resolution) >= pdist.SLAB_MC_MIN_RESOLUTION:
+            verts_d, faces_d = pdist.marching_cubes_sharded(ctx, sdf, thresh)
+        else:
+            verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
         verts = verts_d.cpu().numpy()
         faces = faces_d.cpu().numpy()
         _, calib_inv = calib_pair(calib_tensor)

@@ -152,3 +152,23 @@ def test_sharded_calls_gloo(ws):
     out = [o for (r, _, o) in res if r == 0][0]
     rows = np.arange(30, dtype=np.float32)
     assert np.array_equal(out, np.stack([rows, rows * 2 + 1, -rows], 1))
+
+
+def test_slab_planes_cover_the_cell_layers_once():
+    """Slabs of the sharded marching cubes: contiguous runs of cell layers in rank order, neighbours share one node
+    plane, ranks left without a layer are the last ones."""
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.mesh_util import slab_planes
+    for n0, ws in [(512, 8), (1024, 8), (513, 8), (5, 3), (3, 4), (2, 1), (2, 8), (100, 7)]:
+        runs = slab_planes(n0, ws)
+        assert len(runs) == ws
+        layers, seen_empty = [], False
+        for run in runs:
+            if run is None:
+                seen_empty = True
+                continue
+            assert not seen_empty
+            z, n = run
+            assert n >= 2 and z + n <= n0
+            layers.extend(range(z, z + n - 1))
+        assert layers == list(range(n0 - 1))

@@ -45,7 +45,12 @@ def _worker(rank, ws, port, outdir):
     netMR, data = _build()
     path = os.path.join(outdir, f'mesh_r{rank}.obj')
     verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True)
-    np.savez(os.path.join(outdir, f'out_r{rank}.npz'), verts=verts, faces=faces, color=color)
+    # the same call with marching cubes over one slab per rank (the form `reconstruction` switches to at R >= 1024)
+    from pifuhd_amd import dist as pdist
+    pdist.SLAB_MC_MIN_RESOLUTION = 64
+    verts2, faces2, color2 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True)
+    np.savez(os.path.join(outdir, f'out_r{rank}.npz'), verts=verts, faces=faces, color=color, verts2=verts2, faces2=faces2,
+             color2=color2)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,6 +75,8 @@ def test_gen_mesh_sharded_world2_matches_single_process(tmp_path):
         got = np.load(tmp_path / f'out_r{r}.npz')
         assert np.array_equal(got['verts'], verts) and np.array_equal(got['faces'], faces)
         assert np.array_equal(got['color'], color)
+        assert np.array_equal(got['verts2'], verts) and np.array_equal(got['faces2'], faces)
+        assert np.array_equal(got['color2'], color)
     # rank 0 writes the files, the other ranks do not
     assert open(tmp_path / 'mesh_r0.obj').read() == open(path).read()
     assert not os.path.exists(tmp_path / 'mesh_r1.obj')
@@ -97,11 +104,14 @@ def _rccl_worker(port, outdir):
     got_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
     got_oct, n_got = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
     got = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl.obj'), sharded=True)
+    pdist.SLAB_MC_MIN_RESOLUTION = 64                  # marching cubes through its slab form: four more all-gathers
+    got_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl_slab.obj'), sharded=True)
     t = torch.tensor([3.0], device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     ok = (torch.equal(want_field, got_field) and torch.equal(want_oct, got_oct) and n_want == n_got
           and all(np.array_equal(a, b) for a, b in zip(want, got)) and float(t.item()) == 3.0
+          and all(np.array_equal(a, b) for a, b in zip(want, got_slab))
           and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'rccl.obj')).read())
     with open(os.path.join(outdir, 'rccl_ok.txt'), 'w') as f:
         f.write('%s %s' % (ok, dist.get_backend()))
@@ -139,3 +149,69 @@ def test_bench_dist_selftest_under_torchrun(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['dist_selftest']['backend'] == 'nccl' and line['n_gpus'] == 1 and line['value'] > 0
     assert 'error' not in line['gen_mesh'].get('one_subject_sharded', {'error': 1})
+
+
+def _mc_volume(shape, seed):
+    rs = np.random.RandomState(seed)
+    lin = [-1 + 2 * np.arange(n) / n for n in shape]
+    X, Y, Z = np.meshgrid(*lin, indexing='ij')
+    return (1.0 / (1.0 + np.exp(-(0.55 - np.sqrt(X ** 2 + (0.8 * Y) ** 2 + (1.2 * Z) ** 2)) / 0.04))
+            + 0.25 * (rs.rand(*shape) - 0.5))
+
+
+_MC_CASES = [((61, 40, 36), 1, 0.5), ((3, 9, 9), 2, 0.5), ((2, 6, 6), 3, 0.5), ((24, 16, 16), 4, 0.45)]
+
+
+def _mc_worker(rank, ws, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import dist as pdist
+    from pifuhd_amd.nets import _Ctx
+    ctx = _Ctx('cuda')
+    out = {}
+    for i, (shape, seed, level) in enumerate(_MC_CASES):
+        vol = torch.from_numpy(_mc_volume(shape, seed)).cuda()
+        v, f = pdist.marching_cubes_sharded(ctx, vol, level)
+        out[f'v{i}'], out[f'f{i}'] = v.cpu().numpy(), f.cpu().numpy()
+    # both exceptions must come up on every rank (no rank may be left waiting in a collective)
+    for vol, exc in ((torch.zeros(9, 4, 4, device='cuda'), ValueError), (torch.full((9, 4, 4), 0.5, device='cuda'), RuntimeError)):
+        try:
+            pdist.marching_cubes_sharded(ctx, vol, 0.5)
+            out['raised'] = np.array(0)
+            break
+        except exc:
+            out['raised'] = np.array(1)
+    np.savez(os.path.join(outdir, f'mc_r{rank}.npz'), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_slab_marching_cubes_world3_matches_the_replicated_run(tmp_path):
+    """One axis-0 slab per rank, three ranks sharing the GPU over gloo: every rank must end with the vertices and faces
+    of the single-process marching cubes, bit for bit - also when a rank is left without a cell layer (volumes with 2
+    and 1 layers) - and skimage's exceptions must be raised on all ranks."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mpctx = mp.get_context('spawn')
+    procs = [mpctx.Process(target=_mc_worker, args=(r, 3, port, str(tmp_path))) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=800)
+        assert p.exitcode == 0
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import mesh_util
+    from pifuhd_amd.nets import _Ctx
+    ctx = _Ctx('cuda')
+    for i, (shape, seed, level) in enumerate(_MC_CASES):
+        v, f = mesh_util.marching_cubes_device(ctx, torch.from_numpy(_mc_volume(shape, seed)).cuda(), level)
+        v, f = v.cpu().numpy(), f.cpu().numpy()
+        assert len(v) > 0
+        for r in range(3):
+            got = np.load(tmp_path / f'mc_r{r}.npz')
+            assert np.array_equal(got[f'f{i}'], f) and np.array_equal(got[f'v{i}'].view(np.uint32), v.view(np.uint32)), (i, r)
+            assert int(got['raised']) == 1

@@ -95,6 +95,65 @@ def test_mc_large_vs_oracle(ctx):
     assert _same(v, f, vr, fr)
 
 
+def _mc_slabs(ctx, vol, nslabs, level=0.5):
+    from pifuhd_amd import mesh_util
+    v, f = mesh_util.marching_cubes_slabs(ctx, torch.from_numpy(np.ascontiguousarray(vol)).cuda(), level, nslabs)
+    return v.cpu().numpy(), f.cpu().numpy()
+
+
+def test_slab_marching_cubes_equals_the_whole_volume(ctx, mc_gold, golden_dir):
+    """marching cubes over axis-0 slabs (vertex ownership and numbering of the whole volume, one halo plane of
+    vertex numbers between neighbours) concatenates to the single-volume output bit for bit - on scikit-image's golden
+    volumes, for slab counts that divide the cell layers unevenly, down to one cell layer per slab and to more slabs than
+    cell layers."""
+    g = mc_gold
+    for i in range(int(g['noise_n'][0])):
+        vol = g[f'noise{i}_vol']
+        for ns in (1, 2, 3, vol.shape[0] - 1, vol.shape[0] + 3):
+            v, f = _mc_slabs(ctx, vol, ns)
+            assert _same(v, f, g[f'noise{i}_v'], g[f'noise{i}_f']), (i, ns)
+    for ns in (2, 5, 39):
+        v, f = _mc_slabs(ctx, g['ell40_vol'].astype(np.float64), ns)
+        assert _same(v, f, g['ell40_v'], g['ell40_f']), ns
+    r = np.load(os.path.join(golden_dir, 'recon_small.npz'))
+    v, f = _mc_slabs(ctx, r['oct64_sdf_f32'], 8)
+    assert hashlib.sha256(v.tobytes()).digest() == mc_gold['oct64_v_sha'].tobytes()
+    assert hashlib.sha256(f.tobytes()).digest() == mc_gold['oct64_f_sha'].tobytes()
+    # a non-cubic noisy body, 7 slabs, against the whole-volume kernel path
+    rs = np.random.RandomState(11)
+    lin = [-1 + 2 * np.arange(n) / n for n in (70, 44, 52)]
+    X, Y, Z = np.meshgrid(*lin, indexing='ij')
+    vol = (1.0 / (1.0 + np.exp(-(0.5 - np.sqrt(X ** 2 + (0.7 * Y) ** 2 + (1.3 * Z) ** 2)) / 0.03))
+           + 0.2 * (rs.rand(70, 44, 52) - 0.5))
+    want = _mc(ctx, vol)
+    for ns in (2, 7, 8):
+        assert _same(*_mc_slabs(ctx, vol, ns), *want), ns
+    # the two exceptions come from the totals over the slabs
+    with pytest.raises(ValueError):
+        _mc_slabs(ctx, np.zeros((6, 4, 4), np.float32), 3)
+    with pytest.raises(RuntimeError):
+        _mc_slabs(ctx, np.full((6, 4, 4), 0.5, np.float32), 3)
+    # a surface that lives in one slab only: the other slabs contribute nothing, their ranges still count
+    vol = np.zeros((12, 6, 6), np.float32)
+    vol[9, 3, 3] = 1.0
+    assert _same(*_mc_slabs(ctx, vol, 4), *_mc(ctx, vol))
+
+
+def test_slab_marching_cubes_call_order_is_checked(ctx):
+    from pifuhd_amd import _lib, mesh_util
+    vol = torch.rand(8, 8, 8, device='cuda')
+    step = mesh_util.SlabMarchingCubes(ctx, vol, 0.5, 2, 4)
+    with pytest.raises(_lib.PifuError, match='pifu_mc_slab_count first'):
+        step.verts(0)
+    step.count()
+    with pytest.raises(_lib.PifuError, match='pifu_mc_slab_verts first'):
+        step.faces(None)
+    _, halo = step.verts(0)
+    with pytest.raises(_lib.PifuError, match='needs a halo'):
+        step.faces(None)
+    step.faces(halo)
+
+
 @pytest.mark.parametrize('R,init', [(32, 4), (64, 8), (64, 16), (64, 64), (48, 6)])
 def test_octree_bookkeeping_bit_exact(golden_dir, R, init):
     """The device octree (select / commit kernels) with the analytic field of the golden generator:
