@@ -82,7 +82,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         # (b) independent subjects (different images: a failure may be local to one rank)
         err, t_tot = None, float('inf')
         try:
-            own = synth.synthetic_inputs(1024, 3, seed=rank)
+            own = synth.synthetic_inputs(1024, args.image_channels, seed=rank)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subj{rank}.obj'))
@@ -121,6 +121,8 @@ def main():
     ap.add_argument('--cpu-genmesh-res', type=int, default=128)
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
+    ap.add_argument('--image-channels', type=int, default=6, choices=[3, 6],
+                    help='6 = RGB-D input (RGB || depth, BASELINE config 2; SURVEY C-7), 3 = RGB as the reference is committed')
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
                     help="feature maps from the real encoders (filter) or seeded random maps of the same shape")
     ap.add_argument('--lean', action='store_true', help='skip the coarse MLP layers whose output nobody reads')
@@ -163,14 +165,14 @@ def main():
             pdist.ALWAYS_COLLECTIVE = True
 
     # ---- model + inputs (outside the timed region) ---------------------------------------------------
-    oc = config.coarse_opt()
+    oc = config.coarse_opt(in_image_channels=args.image_channels)
     of = config.fine_opt(oc)
     sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
     netG, netMR = nets.build_nets(oc, of, sd, dev)
     def log(msg):
         print(f'[bench r{rank} {time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
     log('weights ready')
-    data = synth.synthetic_inputs(1024, 3, seed=0)      # one subject: every rank holds the same image + weights
+    data = synth.synthetic_inputs(1024, args.image_channels, seed=0)      # one subject: every rank holds the same image + weights
     if args.features == 'filter':
         netMR.filter_global(data['img_512'].to(dev))
         netMR.filter_local(data['img'].to(dev)[:, None])
@@ -275,7 +277,7 @@ def main():
         'config': {
             'workload': f'dense {res[0]}x{res[1]}x{res[2]} lattice ({R}^3 per GPU, axis-0 chunk-range slabs, RCCL '
                         f'all-gather of the fp32 field), coarse+fine PIFuMRNet query, chunk {args.chunk}, '
-                        f'1024px RGB image + 512px, name-seeded weights',
+                        f'1024px {"RGB-D (6-channel)" if args.image_channels == 6 else "RGB"} image + 512px, name-seeded weights',
             'queries_per_step': total, 'chunk': args.chunk, 'batch_rows': args.batch_rows, 'coarse_tail': 'skipped' if args.lean else 'computed',
             'column_sharing': not args.no_column_sharing,
             'depth_walk': not (args.no_depth_walk or args.no_column_sharing),

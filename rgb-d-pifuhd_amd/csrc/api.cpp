@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
 
 #include <algorithm>
 #include <math.h>
@@ -67,6 +70,7 @@ extern "C" int pifu_ctx_create(int device, pifu_ctx **out)
     }
 #ifdef PIFU_LAB     // tools/lab builds only: kernel selection and diagnostics through the environment
     if (const char *v = getenv("PIFU_GEMM_VARIANT")) c->gemm_variant = atoi(v);
+    if (const char *v = getenv("PIFU_WALK_VARIANT")) c->walk_variant = atoi(v);
     if (const char *v = getenv("PIFU_COLUMN_MODE")) c->col_enable = atoi(v);
     if (const char *v = getenv("PIFU_DEPTH_WALK")) c->walk_enable = atoi(v);
     if (const char *v = getenv("PIFU_PRECISION")) c->precision = atoi(v);
@@ -422,54 +426,73 @@ extern "C" int pifu_write_obj(const char *path, const double *verts, const doubl
 {
     PIFU_REQUIRE(path && (verts || nverts == 0) && (colors || nverts == 0) && (faces || nfaces == 0), PIFU_ERR_INVALID,
                  "pifu_write_obj: null argument");
-    FILE *f = fopen(path, "w");
-    PIFU_REQUIRE(f, PIFU_ERR_INVALID, "pifu_write_obj: cannot open %s", path);
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_write_obj: cannot open %s", path);
     unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
     const int64_t total = nverts + nfaces;
-    const int64_t per = (total + nthreads - 1) / nthreads;
-    std::vector<std::unique_ptr<char[]>> out(nthreads);
-    std::vector<size_t> out_len(nthreads, 0);
+    // The lines are cut into blocks handed out in file order; a thread formats a block into its own (re-used, cache-resident)
+    // buffer, takes the block's file offset from its predecessor's (offset + length) - known as soon as the predecessor is
+    // formatted, before it is written - and writes the block at that offset.  No buffer of the size of the file, no serial
+    // write, and vertex / face blocks of different cost balance by themselves.
+    constexpr int64_t BLOCK = 16384;
+    const int64_t nblocks = (total + BLOCK - 1) / BLOCK;
+    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hw ? hw : 1u, 32u), nblocks));
+    std::unique_ptr<std::atomic<int64_t>[]> offs(new std::atomic<int64_t>[(size_t)nblocks + 1]);
+    for (int64_t i = 0; i <= nblocks; ++i) offs[i].store(i == 0 ? 0 : -1, std::memory_order_relaxed);
+    std::atomic<int64_t> next{0};
+    std::atomic<bool> bad{false};
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; ++t) {
-        pool.emplace_back([&, t]() {
-            const int64_t lo = t * per, hi = std::min(total, lo + per);
-            if (lo >= hi) return;
-            const int64_t nv_here = std::max<int64_t>(0, std::min(hi, nverts) - lo), nf_here = (hi - lo) - nv_here;
-            size_t slow = 0;      // values outside the fast formatter's range need up to SLOW_CHARS characters each
-            for (int64_t i = lo; i < lo + nv_here; ++i)
-                for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
-            out[t].reset(new char[(size_t)nv_here * 168 + (size_t)nf_here * 40 + slow * SLOW_CHARS + 64]);    // uninitialised on purpose
-            char *const base = out[t].get();
-            char *o = base;
-            for (int64_t i = lo; i < hi; ++i) {
-                if (i < nverts) {
-                    const double *v = verts + 3 * i, *c = colors + 3 * i;
-                    *o++ = 'v';
-                    for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
-                    for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
-                    *o++ = '\n';
-                } else {
-                    const int32_t *tr = faces + 3 * (i - nverts);
-                    const int idx[3] = {tr[0] + 1, tr[2] + 1, tr[1] + 1};
-                    *o++ = 'f';
-                    for (int k = 0; k < 3; ++k) {
-                        *o++ = ' ';
-                        if (idx[k] < 0) { *o++ = '-'; o = put_uint(o, (uint64_t)(-(int64_t)idx[k])); }
-                        else o = put_uint(o, (uint64_t)idx[k]);
+        pool.emplace_back([&]() {
+            constexpr size_t FAST = (size_t)BLOCK * 168 + 64;         // a block without out-of-range values
+            std::unique_ptr<char[]> own(new char[FAST]);               // uninitialised on purpose
+            std::unique_ptr<char[]> big;
+            for (;;) {
+                const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+                if (b >= nblocks) break;
+                const int64_t lo = b * BLOCK, hi = std::min(total, lo + BLOCK);
+                const int64_t nv_here = std::max<int64_t>(0, std::min(hi, nverts) - lo);
+                size_t slow = 0;      // values outside the fast formatter's range need up to SLOW_CHARS characters each
+                for (int64_t i = lo; i < lo + nv_here; ++i)
+                    for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
+                char *base = own.get();
+                if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
+                char *o = base;
+                for (int64_t i = lo; i < hi; ++i) {
+                    if (i < nverts) {
+                        const double *v = verts + 3 * i, *c = colors + 3 * i;
+                        *o++ = 'v';
+                        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
+                        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
+                        *o++ = '\n';
+                    } else {
+                        const int32_t *tr = faces + 3 * (i - nverts);
+                        const int idx[3] = {tr[0] + 1, tr[2] + 1, tr[1] + 1};
+                        *o++ = 'f';
+                        for (int k = 0; k < 3; ++k) {
+                            *o++ = ' ';
+                            if (idx[k] < 0) { *o++ = '-'; o = put_uint(o, (uint64_t)(-(int64_t)idx[k])); }
+                            else o = put_uint(o, (uint64_t)idx[k]);
+                        }
+                        *o++ = '\n';
                     }
-                    *o++ = '\n';
                 }
+                int64_t off;
+                while ((off = offs[b].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+                size_t left = (size_t)(o - base);
+                offs[b + 1].store(off + (int64_t)left, std::memory_order_release);
+                const char *src = base;
+                while (left) {
+                    const ssize_t w = pwrite(fd, src, left, (off_t)off);
+                    if (w <= 0) { bad.store(true); break; }
+                    src += w; off += w; left -= (size_t)w;
+                }
+                big.reset();
             }
-            out_len[t] = (size_t)(o - base);
         });
     }
     for (auto &th : pool) th.join();
-    bool bad = false;
-    for (int t = 0; t < nthreads; ++t)
-        if (out_len[t] && fwrite(out[t].get(), 1, out_len[t], f) != out_len[t]) bad = true;
-    bad = bad || ferror(f);
-    fclose(f);
-    PIFU_REQUIRE(!bad, PIFU_ERR_INVALID, "pifu_write_obj: write error on %s", path);
+    if (close(fd) != 0) bad.store(true);
+    PIFU_REQUIRE(!bad.load(), PIFU_ERR_INVALID, "pifu_write_obj: write error on %s", path);
     return PIFU_OK;
 }

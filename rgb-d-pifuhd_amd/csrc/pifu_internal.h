@@ -130,6 +130,7 @@ struct pifu_ctx {
     void *tile_ctr = nullptr;             // k_mlp_gemm_dyn work-queue counters: ring of [8] int slots
     int tile_ctr_next = 0;
     int gemm_variant = 5;                 // kernel / schedule selection (env PIFU_GEMM_VARIANT)
+    int walk_variant = 0;                 // 1 = round-1 depth-walk kernel (env PIFU_WALK_VARIANT)
 #endif
     void *clock_buf = nullptr;            // pifu_clock_probe: [8 XCDs][shader ticks, real-time ticks]
     // arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default), 1 = bf16 x 3 split precision on the bf16 matrix cores

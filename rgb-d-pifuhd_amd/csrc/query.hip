@@ -1507,7 +1507,11 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 wa.flip_key = w.flip_key; wa.flip_d = w.flip_d; wa.nflips = w.nflips;
                 wa.zf = pl.zf; wa.seg_row0 = w.seg_row0; wa.nseg = nseg; wa.g = g; wa.C0 = C0; wa.N1 = N1;
                 wa.Y = b.out[i]; wa.ldy = l.cout_pad; wa.partial_seg = stats ? w.partial_seg : nullptr;
-                hipLaunchKernelGGL(k_walk<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+#ifdef PIFU_LAB
+                if (ctx->walk_variant == 1) hipLaunchKernelGGL(k_walk_v1<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                else
+#endif
+                hipLaunchKernelGGL(k_walk<16>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
                 if (stats) {
                     const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                     hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.partial_seg,

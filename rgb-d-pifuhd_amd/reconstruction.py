@@ -64,8 +64,9 @@ class _Subject:
         coarse = data['img_512'].to(device=dev)
         net.filter_global(coarse)
         net.filter_local(self.image_fine[:, None])
-        # the strip saved beside the mesh: input | front normal | back normal, as far as the coarse net predicts them
-        tiles = [coarse] + [t for t in (net.netG.nmlF, net.netG.nmlB) if t is not None]
+        # the strip saved beside the mesh: input | front normal | back normal, as far as the coarse net predicts them; of an
+        # RGB-D input (6 channels, SURVEY C-7) the colour half is shown
+        tiles = [coarse[:, :3]] + [t for t in (net.netG.nmlF, net.netG.nmlB) if t is not None]
         self.strip = torch.cat(tiles, 0)
         self.b_min, self.b_max = data['b_min'], data['b_max']
 

@@ -82,6 +82,15 @@ def test_obj_writer_host_only(lib, tmp_path):
     p = tmp_path / 'a.obj'
     mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
     assert p.read_text() == O.obj_text(v, f, c)
+    # several blocks of the ordered block writer (16 384 lines each), a block straddling the vertex / face boundary, blocks
+    # with and without out-of-range values, an empty mesh
+    v = np.concatenate([rs.randn(40000, 3) * 3, np.array([[1.7e308, -1e300, np.nan]]), rs.randn(9000, 3)])
+    c = rs.rand(len(v), 3)
+    f = rs.randint(0, len(v), size=(70001, 3)).astype(np.int32)
+    mesh_util.save_obj_mesh_with_color(str(p), v, f, c)
+    assert p.read_text() == O.obj_text(v, f, c)
+    mesh_util.save_obj_mesh_with_color(str(p), v[:0], f[:0], c[:0])
+    assert p.read_text() == ''
 
 
 def test_checkpoint_io_roundtrip(tmp_path):

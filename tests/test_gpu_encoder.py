@@ -105,6 +105,25 @@ def test_rgbd_six_channel_input(golden_dir):
     assert np.abs(netMR.get_preds()[0, 0].cpu().numpy() - gold['fine']).max() < 1e-4
 
 
+def test_gen_mesh_accepts_rgbd_input(tmp_path):
+    """The whole `gen_mesh` on a 6-channel subject (what bench.py runs by default): the mesh comes out and the strip saved
+    beside it shows the colour half of the input next to the two predicted normal maps."""
+    from pifuhd_amd import config, nets, reconstruction, synth
+    oc = config.coarse_opt(in_image_channels=6)
+    of = config.fine_opt(oc)
+    of.loadSizeBig = 128
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=0.16, perturb=True)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = synth.synthetic_inputs(128, 6, seed=2)
+    data['img_512'] = synth.synthetic_image(64, 6, seed=2)
+    netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
+    verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, str(tmp_path / 'rgbd.obj'))
+    assert len(verts) > 100 and len(faces) > 100 and color.shape == verts.shape
+    from PIL import Image
+    assert Image.open(tmp_path / 'rgbd.png').size == (3 * 64, 64)
+
+
 def test_reloading_weights_into_a_live_net_refreshes_every_derived_buffer():
     """State dict A, filter, then state dict B into the SAME nets: the outputs must equal those of fresh nets loaded
     with B (folded eval-mode BatchNorm scale / shift, packed conv weights and the repacked 7x7 output conv are all

@@ -1,7 +1,7 @@
 """Depth walk on/off on the same lattice: throughput and max difference of the occupancy field.
 usage: python tools/ab_walk.py [res]"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, _lib, dist as pdist

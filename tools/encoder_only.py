@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, time
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth

@@ -1,6 +1,6 @@
 """Where the host-side time of gen_mesh 512^3 goes (copies, numpy transforms) between the GPU phases."""
 import sys, time, os, tempfile
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, reconstruction as recon, mesh_util
