@@ -109,6 +109,7 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }
 #define PIFU_STORE_AUX 2
 #endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p)
@@ -677,7 +678,7 @@ __global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int grou
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_last_layer: the Cout = 1 layer + sigmoid + bounding-box mask.  16 lanes per point row.
+// k_last_layer: the Cout = 1 layer + sigmoid + bounding-box mask.  8 or 16 lanes per point row.
 // ------------------------------------------------------------------------------------------------
 struct LastArgs {
     Seg seg[3];
@@ -696,10 +697,13 @@ struct LastArgs {
     const int *colidx;
 };
 
-__global__ void k_last_layer(const LastArgs a)
+// LPR lanes per point row: 8 for the usual 128-wide input (four independent 16-byte loads per lane in flight: the kernel
+// only streams the rows once, so what it needs is bytes in flight), 16 otherwise.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_last_layer(const LastArgs a)
 {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+    const int sub = threadIdx.x & (LPR - 1);
     if (row >= a.rows) return;
     const int P = a.g.tpc * BM;
     const int c = (int)(row / P), local = (int)(row % P);
@@ -709,7 +713,8 @@ __global__ void k_last_layer(const LastArgs a)
     for (int sg = 0; sg < a.nseg; ++sg) {
         const Seg &S = a.seg[sg];
         const float *x = S.ptr + (size_t)row * S.ld;
-        for (int k = sub * 4; k < S.width; k += 64) {
+#pragma unroll 4
+        for (int k = sub * 4; k < S.width; k += LPR * 4) {
             float4 v = *reinterpret_cast<const float4 *>(x + k);
             if (S.mode == 1) {
                 const float4 sc = *reinterpret_cast<const float4 *>(S.scale + (size_t)c * S.sld + k);
@@ -725,13 +730,21 @@ __global__ void k_last_layer(const LastArgs a)
         kbase += S.width;
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int o = LPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
     if (sub == 0 && valid) {
         if (a.colQ) dot += fmaf(a.wz0, a.zf[row], a.colQ[(size_t)a.colidx[row] * a.ldq + a.qoff]);
         float p = 1.f / (1.f + expf(-(dot + a.bias)));
         if (a.mask_bit && !(a.mask[row] & a.mask_bit)) p = 0.f;     // pred * in_bb
         a.out[(int64_t)c * a.g.chunk + local] = p;
     }
+}
+
+static void launch_last_layer(const LastArgs &a, hipStream_t st)
+{
+    int widest = 0;
+    for (int s = 0; s < a.nseg; ++s) widest = a.seg[s].width > widest ? a.seg[s].width : widest;
+    if (widest <= 128) hipLaunchKernelGGL(k_last_layer<8>, dim3((unsigned)((a.rows * 8 + 255) / 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_last_layer<16>, dim3((unsigned)((a.rows * 16 + 255) / 256)), dim3(256), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1233,7 +1246,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
             a.w = l.w; a.bias = l.host_bias0; a.mask = mask; a.mask_bit = mask_bit; a.out = pred_out; a.rows = rows; a.g = g;
-            hipLaunchKernelGGL(k_last_layer, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+            launch_last_layer(a, st);
         }
     }
     PIFU_HIP(hipGetLastError());
@@ -1507,11 +1520,18 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 wa.flip_key = w.flip_key; wa.flip_d = w.flip_d; wa.nflips = w.nflips;
                 wa.zf = pl.zf; wa.seg_row0 = w.seg_row0; wa.nseg = nseg; wa.g = g; wa.C0 = C0; wa.N1 = N1;
                 wa.Y = b.out[i]; wa.ldy = l.cout_pad; wa.partial_seg = stats ? w.partial_seg : nullptr;
-#ifdef PIFU_LAB
-                if (ctx->walk_variant == 1) hipLaunchKernelGGL(k_walk_v1<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+#ifdef PIFU_LAB     // tools/walk_ab.sh
+                const int wv = ctx->walk_variant;
+                if (wv == 1) hipLaunchKernelGGL(k_walk_v1<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                else if (wv == 3) hipLaunchKernelGGL((k_walk<8, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
+                else if (wv == 4) hipLaunchKernelGGL((k_walk<16, 1>), dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                else if (wv == 5) hipLaunchKernelGGL((k_walk<32, 1>), dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                else if (wv == 6) hipLaunchKernelGGL((k_walk_pair<16>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
+                else if (wv == 8) hipLaunchKernelGGL((k_walk<32, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
                 else
 #endif
-                hipLaunchKernelGGL(k_walk<16>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                if (N1 % 512 == 0) hipLaunchKernelGGL((k_walk<16, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
+                else hipLaunchKernelGGL((k_walk<16, 1>), dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
                 if (stats) {
                     const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                     hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.partial_seg,
@@ -1552,7 +1572,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 a.colQ = T.Q[L]; a.ldq = T.ldq[L]; a.qoff = l.col_off; a.wz0 = L == 0 ? l.host_wz0 : 0.f;
                 a.zf = pl.zf; a.colidx = pl.colidx;
             }
-            hipLaunchKernelGGL(k_last_layer, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+            launch_last_layer(a, st);
         }
     }
     PIFU_HIP(hipGetLastError());
