@@ -60,6 +60,7 @@ struct GemmArgs {
     int ldy;
     float2 *partial;  // [ntm][ldy] (sum, sum of squares) over the valid rows of the tile, or null
     int ntm, ntn;
+    int ktot;         // K of this launch (a multiple of 32): the sum of the segment widths; <= ldw (set by run_gemm)
     ChunkGeom g;
 #ifdef PIFU_LAB
     unsigned long long *stamps;   // diagnostic kernels only: [64 blocks][40 steps][4] s_memtime stamps
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 
     const int kq = tid & 7, sr = tid >> 3;        // staging: float4 column kq of rows sr + 32 p
     const unsigned kb = kq * 16;
-    const int nsteps = a.ldw / TBK;
+    const int nsteps = a.ktot / TBK;
     const unsigned ldw4 = (unsigned)a.ldw * 4u;
     const __amdgpu_buffer_rsrc_t rW = buf_rsrc(a.W + (size_t)col0 * a.ldw);
     const unsigned voW = (unsigned)sr * ldw4 + kb;
@@ -247,7 +248,22 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
     const int h = lane >> 5, j = lane & 31;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     BUF_GLOAD(0)
-    if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
+    if (a.colQ && a.ldq == 0) {
+        // per-point path: the depth feature is the one input column after the image features; it enters as the rank-1 start
+        // value wz * z instead of a 32-wide K step of its own (the table is a single row of zeros: the same fmaf as below)
+        const __amdgpu_buffer_rsrc_t rZ = buf_rsrc(a.zf + row0);
+        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u;
+        const float wz0 = a.colwz[col0 + wn * 64 + j], wz1 = a.colwz[col0 + wn * 64 + 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+            const float zA = buf_load1(rZ, vrow, so), zB = buf_load1(rZ, vrow, so + 128u);
+            acc00[r] = fmaf(wz0, zA, 0.f);
+            acc01[r] = fmaf(wz1, zA, 0.f);
+            acc10[r] = fmaf(wz0, zB, 0.f);
+            acc11[r] = fmaf(wz1, zB, 0.f);
+        }
+    } else if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
         const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
         const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + a.qoff + col0);     // descriptors stay block-uniform (SGPRs)
         const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
     const int wq = tid & 3, wr = tid >> 2;       // W staging: 8 bf16 (16 B) column wq of rows wr + 64 p
     const int b1 = a.seg[0].width;
     const int b2 = b1 + (a.nseg > 1 ? a.seg[1].width : 0);
-    const int nsteps = a.ldw / TBK;
+    const int nsteps = a.ktot / TBK;
 
     // Operands are prefetched TWO K steps ahead into two register sets (step j lives in set j & 1): with the short
     // bf16 MFMA phase a one-step-ahead prefetch would stall on the global-load latency at every staging pass.
@@ -772,6 +788,7 @@ struct SampleArgs {
     float *featc; int ldc;
     float *finef; int ldf;
     uint8_t *mask;
+    float *zf;                // per-point sampler: the depth feature once more as a column of its own (or null)
     int64_t rows;
     ChunkGeom g;
 };
@@ -823,7 +840,7 @@ __global__ void k_sample(const SampleArgs a)
     if (!valid) {   // padded row: zero features keep every downstream value finite; excluded from statistics
         for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
         if (ff_out && lane * 4 < a.ldf) *reinterpret_cast<float4 *>(ff_out + lane * 4) = make_float4(0, 0, 0, 0);
-        if (lane == 0) a.mask[row] = 0;
+        if (lane == 0) { a.mask[row] = 0; if (a.zf) a.zf[row] = 0.f; }
         return;
     }
     const int64_t i = a.src.first + (int64_t)c * a.g.chunk + local;   // point index within the call
@@ -874,6 +891,7 @@ __global__ void k_sample(const SampleArgs a)
     // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
     for (int col = a.Cc + lane; col < a.ldc; col += 64)
         fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
+    if (a.zf && lane == 0) a.zf[row] = (z * a.z_mul) / a.z_div;
 
     if (ff_out) {
         bilinear_setup(x, y, a.Wf, a.Hf, off, wt);
@@ -1201,6 +1219,10 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
     // the skip-concatenated MLP input ("feature" in MLP.forward)
     Seg feat[2];
     int nfeat = 0;
+    // coarse level: the input is [image features | z].  When the image features fill whole K steps, z does not get a
+    // (31/32 empty) step of its own: the GEMM covers the image features and starts from wz * z (GemmArgs::colQ with ldq = 0)
+    const int cimg = m.dims[0] - 1;
+    const bool zrank1 = L == 0 && cimg > 0 && cimg % BK == 0 && pl.ldc == cimg + BK && m.layer[0].wz != nullptr;
     if (L == 0) {
         feat[0] = Seg{pl.featc, ctx->ident_scale, ctx->ident_shift, pl.ldc, pl.ldc, 0, 0};
         nfeat = 1;
@@ -1214,7 +1236,8 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
         Seg segs[3];
         int ns = 0;
         if (i > 0) segs[ns++] = make_prev_seg(ctx, m, b, i - 1);
-        if (i == 0 || m.res[i])
+        const bool has_feat = i == 0 || m.res[i];
+        if (has_feat)
             for (int f = 0; f < nfeat; ++f) segs[ns++] = feat[f];
         int ksum = 0;
         for (int s = 0; s < ns; ++s) ksum += segs[s].width;
@@ -1223,6 +1246,11 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             GemmArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
+            if (zrank1 && has_feat) {       // the feature segment is the last one: its z step (and the weight columns of it) drop out
+                a.seg[ns - 1].width = cimg;
+                a.colQ = ctx->ident_shift; a.ldq = 0; a.qoff = 0; a.colwz = l.wz;
+                a.zf = pl.zf; a.colidx = pl.colidx;
+            }
             a.W = l.w; a.ldw = l.kpad; a.bias = l.bias;
             a.Y = b.out[i]; a.ldy = l.cout_pad;
             const bool stats = (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN);
@@ -1389,6 +1417,8 @@ static void fill_step_table(GemmArgs &a, int64_t rows)
 static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
 {
     const int nblocks = (int)round_up(a.ntm, 8) * a.ntn;
+    a.ktot = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) a.ktot += a.seg[sgi].width;
     fill_step_table(a, (int64_t)a.ntm * BM);
     if (ctx->precision != 0) {
         int rc = split_planes(ctx, a.W, (size_t)a.ntn * BN * a.ldw, &a.Whi, &a.Wlo, st);
@@ -1726,10 +1756,13 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             continue;
         }
         // the chunk geometry indexes points relative to the batch start: src.first already points there
+        rc = build_column_weights(ctx, 0);       // wz of the coarse layers (launch_level: the z step as a rank-1 start value)
+        if (rc != PIFU_OK) return rc;
         {
             hipEvent_t es;
             rc = pifu_prof_begin(ctx, PIFU_PROF_SAMPLER, st, &es);
             if (rc != PIFU_OK) return rc;
+            sa.zf = pl.zf;
             hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
             // algorithmic bytes of the per-point sampler: 4 bilinear taps x (coarse + fine channels) gathered, one MLP
             // input row (coarse + fine) written, per valid point
