@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--cpu-genmesh-res', type=int, default=128)
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
+    ap.add_argument('--no-smooth-genmesh', action='store_true', help='skip the second gen_mesh subject (stock-scale MLP weights)')
     ap.add_argument('--image-channels', type=int, default=6, choices=[3, 6],
                     help='6 = RGB-D input (RGB || depth, BASELINE config 2; SURVEY C-7), 3 = RGB as the reference is committed')
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
@@ -503,6 +504,26 @@ def main():
                 out['gen_mesh'] = {'error': repr(e)}
             finally:
                 _lib.call('pifu_profile_enable', h, 0)
+            # the same call on a SMOOTHER subject: the MLP weights drawn at torch's stock scale (std 0.02 instead of the 0.16
+            # that gives the headline subject its rough, multi-million-vertex surface).  Fewer points survive the octree and
+            # fewer vertices need normals, so the per-image work (encoders) and the fixed costs weigh more - the other end of
+            # what config 3 can look like.  Reported beside the headline subject, never instead of it.
+            if not args.no_smooth_genmesh and 'error' not in out['gen_mesh']:
+                try:
+                    sd2 = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.02)
+                    netG2, netMR2 = nets.build_nets(oc, of, sd2, dev)
+                    netMR2.filter_global(data['img_512'].to(dev))
+                    netMR2.filter_local(data['img'].to(dev)[:, None])
+                    synth.calibrate_occupancy_bias(netMR2, calib, sd2, 0.3)
+                    recon.gen_mesh(128, netMR2, dev, data, os.path.join(td, 'warm2.obj'))
+                    t2 = {}
+                    recon.gen_mesh(args.genmesh_res, netMR2, dev, data, os.path.join(td, 'mesh2.obj'), timings=t2)
+                    out['gen_mesh']['smoother_subject'] = {
+                        'mlp_weight_std': 0.02, **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t2.items()}}
+                    log(f"gen_mesh, smoother subject: {t2.get('total_s'):.3f} s, {t2.get('n_verts')} vertices")
+                    del netG2, netMR2
+                except Exception as e:
+                    out['gen_mesh']['smoother_subject'] = {'error': repr(e)}
 
             # ---- CPU baseline for the second half of the metric: the oracle's gen_mesh phases (octree grid evaluation,
             # serial Lewiner marching cubes, the calc_normal colour loop) at a resolution the host finishes in seconds,

@@ -142,7 +142,7 @@ def test_bench_dist_selftest_under_torchrun(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), 'bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--res', '64',
            '--genmesh-res', '64', '--batch-rows', '262144', '--dist-selftest', '--no-cpu-baseline', '--no-split-precision',
-           '--no-lean-pass', '--no-canonical']
+           '--no-lean-pass', '--no-canonical', '--no-smooth-genmesh']
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
