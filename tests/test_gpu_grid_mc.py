@@ -139,6 +139,22 @@ def test_slab_marching_cubes_equals_the_whole_volume(ctx, mc_gold, golden_dir):
     assert _same(*_mc_slabs(ctx, vol, 4), *_mc(ctx, vol))
 
 
+def test_slab_marching_cubes_on_a_1024_cube_volume(ctx):
+    """BASELINE config 5's grid size on one GPU: a 1024^3 float64 SDF (8.6 GB, built on the device) meshed as 8 axis-0 slabs
+    - what 8 ranks would each do with 1/8 of the index volume - equals the single-volume marching cubes bit for bit
+    (vertex numbers up to ~2.5 M cross the slab boundaries through the halo planes)."""
+    from pifuhd_amd import mesh_util
+    R = 1024
+    lin = torch.linspace(-1.0, 1.0 - 2.0 / R, R, device='cuda', dtype=torch.float64)
+    x, y, z = lin[:, None, None], lin[None, :, None], lin[None, None, :]
+    vol = torch.sigmoid((0.45 - torch.sqrt((0.9 * x) ** 2 + (0.5 * y) ** 2 + (1.4 * z) ** 2)) / 0.01)
+    vol += 0.02 * torch.sin(91.0 * x + 40.0 * y) * torch.cos(67.0 * z)            # ripples: ambiguous cells near the surface
+    del x, y, z
+    v, f = mesh_util.marching_cubes_device(ctx, vol, 0.5)
+    vs, fs = mesh_util.marching_cubes_slabs(ctx, vol, 0.5, 8)
+    assert len(v) > 1_000_000 and torch.equal(f, fs) and torch.equal(v.view(torch.int32), vs.view(torch.int32))
+
+
 def test_slab_marching_cubes_call_order_is_checked(ctx):
     from pifuhd_amd import _lib, mesh_util
     vol = torch.rand(8, 8, 8, device='cuda')
