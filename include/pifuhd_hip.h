@@ -198,6 +198,13 @@ int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *
 int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
                              float delta, float *normals, float *pred4, pifu_stream stream);
 
+/* ---- vertex back-transform of reconstruction() (mesh_util.py:87-89): verts = (trans_mat[:3,:3] @ verts.T + trans_mat[:3,3:4]).T
+ * in float64 on the float32 marching-cubes vertices.  verts: device fp32 [n][3]; mat: HOST double [12] = rows of the 3x4
+ * trans_mat; out: device double [n][3].  Per component: the three products accumulated by FMA in k order starting from the
+ * first product, the translation added last - what numpy's matmul (a BLAS dgemm) evaluates for this K = 3 product (the host
+ * wrapper checks a sample of the vertices against numpy on the machine it runs on and keeps numpy's result if they differ). */
+int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream);
+
 /* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
  * reconstruction.py:112-115): bilinear grid_sample, align_corners=True, zero padding.
  * feat: device fp32 NCHW [C][H][W] (batch 1); uv: device fp32 [2][n]; out: device fp32 [C][n]. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     'pifu_eval_grid': (_i32, [_p, _i32, _p, _p, _i64, _i32, _d, _i32, _p, _p, C.POINTER(_i64), _p]),
     'pifu_mc_count': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _d, C.POINTER(_i64), C.POINTER(_i64), _p]),
     'pifu_mc_emit': (_i32, [_p, _p, _p, _p]),
+    'pifu_transform_verts': (_i32, [_p, _p, _i64, _p, _p, _p]),
     'pifu_mc_slab_count': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _d, C.POINTER(_i64), C.POINTER(_i64),
                                   C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     'pifu_mc_slab_verts': (_i32, [_p, _p, _i64, _p, _p]),

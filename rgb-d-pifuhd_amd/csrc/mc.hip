@@ -633,3 +633,31 @@ extern "C" int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *
     ctx->mc.valid = false;
     return PIFU_OK;
 }
+
+// ---- vertex back-transform (mesh_util.py:87-89) ------------------------------------------------------------------------------
+namespace {
+struct Mat34 { double m[12]; };
+__global__ void k_transform_verts(const float *verts, int64_t n, const Mat34 t, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = (double)verts[3 * i], y = (double)verts[3 * i + 1], z = (double)verts[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double *m = t.m + 4 * r;
+        out[3 * i + r] = __dadd_rn(__fma_rn(m[2], z, __fma_rn(m[1], y, __dmul_rn(m[0], x))), m[3]);
+    }
+}
+}  // namespace
+
+extern "C" int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && mat && (n == 0 || (verts && out)) && n >= 0, PIFU_ERR_INVALID, "pifu_transform_verts: bad argument");
+    if (n == 0) return PIFU_OK;
+    PIFU_HIP(hipSetDevice(ctx->device));
+    Mat34 t;
+    for (int k = 0; k < 12; ++k) t.m[k] = mat[k];
+    hipLaunchKernelGGL(k_transform_verts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, n, t, out);
+    PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}

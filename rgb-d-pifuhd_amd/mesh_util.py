@@ -172,6 +172,31 @@ def marching_cubes_slabs(ctx, volume, level, nslabs):
     return torch.cat(verts), torch.cat(faces)
 
 
+transform_fallbacks = 0      # times transform_verts() had to keep numpy's result (diagnostic)
+
+
+def transform_verts(ctx, verts_d, trans_mat):
+    """`(trans_mat[:3, :3] @ verts.T + trans_mat[:3, 3:4]).T` in float64 (`mesh_util.py:87-89`) on the device
+    (`pifu_transform_verts`), returned as a host array.  The kernel evaluates the K = 3 products the way numpy's matmul does
+    (FMA chain in k order, translation added afterwards); a sample of the vertices is recomputed with numpy itself and, should
+    the BLAS of this machine round differently, numpy's result for all vertices is returned instead."""
+    n = verts_d.shape[0]
+    rows = np.ascontiguousarray(trans_mat[:3, :4], dtype=np.float64)
+    out_d = torch.empty(n, 3, device=verts_d.device, dtype=torch.float64)
+    _lib.call('pifu_transform_verts', ctx.h, _ptr(verts_d), n, rows.ctypes.data_as(C.c_void_p), _ptr(out_d),
+              _stream_ptr(ctx.device))
+    out = out_d.cpu().numpy()
+    step = max(n // 2048, 1)
+    sample = verts_d[::step].cpu().numpy()
+    want = (np.matmul(trans_mat[:3, :3], sample.T) + trans_mat[:3, 3:4]).T
+    if not np.array_equal(out[::step], want):                  # pragma: no cover - depends on the host's BLAS
+        global transform_fallbacks
+        transform_fallbacks += 1
+        verts = verts_d.cpu().numpy()
+        return (np.matmul(trans_mat[:3, :3], verts.T) + trans_mat[:3, 3:4]).T
+    return out
+
+
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
                    num_samples=10000, transform=None, return_sdf=False, sharded=False):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
@@ -196,14 +221,13 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
             verts_d, faces_d = pdist.marching_cubes_sharded(ctx, sdf, thresh)
         else:
             verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
-        verts = verts_d.cpu().numpy()
         faces = faces_d.cpu().numpy()
         _, calib_inv = calib_pair(calib_tensor)
         mat = np.eye(4)
         mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
         mat[0:3, 3] = -1.0
         trans_mat = np.matmul(calib_inv, mat)
-        verts = (np.matmul(trans_mat[:3, :3], verts.T) + trans_mat[:3, 3:4]).T          # mesh_util.py:87-89
+        verts = transform_verts(ctx, verts_d, trans_mat)                                  # mesh_util.py:87-89
         if np.linalg.det(trans_mat[:3, :3]) < 0.0:
             faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
         normals = np.zeros((0, 3), np.float32)

@@ -4,10 +4,10 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, reconstruction as recon, mesh_util
-oc = config.coarse_opt(); of = config.fine_opt(oc)
+oc = config.coarse_opt(in_image_channels=6); of = config.fine_opt(oc)
 sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
 netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
-data = synth.synthetic_inputs(1024, 3, seed=0)
+data = synth.synthetic_inputs(1024, 6, seed=0)
 netMR.filter_global(data['img_512'].cuda()); netMR.filter_local(data['img'].cuda()[:, None])
 synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3)
 with tempfile.TemporaryDirectory() as td:
