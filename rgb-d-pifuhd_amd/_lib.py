@@ -72,6 +72,8 @@ SIGNATURES = {
     'pifu_profile_read': (_i32, [_p, _i32, C.POINTER(_d), C.POINTER(_i64), C.POINTER(_d), _i32]),
     'pifu_clock_probe': (_i32, [_p, _p, _p]),
     'pifu_write_obj': (_i32, [C.c_char_p, _p, _p, _i64, _p, _i64]),
+    'pifu_obj_begin': (_i32, [C.c_char_p, _p, _i64, _i64, _i64, C.POINTER(_p)]),
+    'pifu_obj_finish': (_i32, [_p, _p, _p, _i64]),
 }
 
 _lib = None

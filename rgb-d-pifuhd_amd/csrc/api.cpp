@@ -421,6 +421,179 @@ inline char *put_fixed4(char *o, double x)
 
 }  // namespace
 
+namespace {
+
+constexpr int64_t OBJ_BLOCK = 16384;        // lines per block of the writer
+
+inline int obj_threads(int64_t nblocks)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hw ? hw : 1u, 32u), nblocks));
+}
+
+inline bool write_all(int fd, const char *src, size_t left, int64_t off)
+{
+    while (left) {
+        const ssize_t w = pwrite(fd, src, left, (off_t)off);
+        if (w <= 0) return false;
+        src += w; off += w; left -= (size_t)w;
+    }
+    return true;
+}
+
+// 'v x y z r g b' lines of vertices [lo, hi) into o; returns the end
+inline char *format_vertex_lines(char *o, const double *verts, const double *colors, int64_t lo, int64_t hi)
+{
+    for (int64_t i = lo; i < hi; ++i) {
+        const double *v = verts + 3 * i, *c = colors + 3 * i;
+        *o++ = 'v';
+        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
+        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
+        *o++ = '\n';
+    }
+    return o;
+}
+
+// values of vertices [lo, hi) outside the fast formatter's range (each needs up to SLOW_CHARS characters)
+inline size_t count_slow_values(const double *verts, const double *colors, int64_t lo, int64_t hi)
+{
+    size_t slow = 0;
+    for (int64_t i = lo; i < hi; ++i)
+        for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
+    return slow;
+}
+
+// 'f a b c' lines of triangles [lo, hi): 1-based (f0, f2, f1); triangle i at faces[i * row_stride + k * col_stride]
+inline char *format_face_lines(char *o, const int32_t *faces, int64_t row_stride, int64_t col_stride, int64_t lo, int64_t hi)
+{
+    for (int64_t i = lo; i < hi; ++i) {
+        const int32_t *tr = faces + i * row_stride;
+        const int idx[3] = {tr[0] + 1, tr[2 * col_stride] + 1, tr[col_stride] + 1};
+        *o++ = 'f';
+        for (int k = 0; k < 3; ++k) {
+            *o++ = ' ';
+            if (idx[k] < 0) { *o++ = '-'; o = put_uint(o, (uint64_t)(-(int64_t)idx[k])); }
+            else o = put_uint(o, (uint64_t)idx[k]);
+        }
+        *o++ = '\n';
+    }
+    return o;
+}
+
+constexpr size_t OBJ_VERTEX_LINE = 168, OBJ_FACE_LINE = 40;      // upper bounds of a line without out-of-range values
+
+// Two-phase writer.  The face lines depend on the triangles only, so pifu_obj_begin starts formatting them on worker threads
+// (into memory, block by block) while the caller is still computing the vertex colours; pifu_obj_finish formats the vertex
+// lines - each thread takes blocks in file order, learns a block's file offset from its predecessor's (offset + length) as
+// soon as that one is FORMATTED, and writes the block at its own offset - and then writes the face blocks behind them.
+struct ObjWriter {
+    int fd = -1;
+    std::string path;
+    const int32_t *faces = nullptr;
+    int64_t nfaces = 0, row_stride = 3, col_stride = 1;
+    int64_t nblocks = 0;
+    std::vector<std::unique_ptr<char[]>> text;
+    std::vector<size_t> len;
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+
+    void format_faces()
+    {
+        for (;;) {
+            const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks) break;
+            const int64_t lo = b * OBJ_BLOCK, hi = std::min(nfaces, lo + OBJ_BLOCK);
+            text[b].reset(new char[(size_t)(hi - lo) * OBJ_FACE_LINE + 16]);
+            char *o = format_face_lines(text[b].get(), faces, row_stride, col_stride, lo, hi);
+            len[b] = (size_t)(o - text[b].get());
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride,
+                              void **writer)
+{
+    PIFU_REQUIRE(path && writer && (faces || nfaces == 0) && nfaces >= 0, PIFU_ERR_INVALID, "pifu_obj_begin: bad argument");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_obj_begin: cannot open %s", path);
+    ObjWriter *w = new ObjWriter();
+    w->fd = fd; w->path = path; w->faces = faces; w->nfaces = nfaces; w->row_stride = row_stride; w->col_stride = col_stride;
+    w->nblocks = (nfaces + OBJ_BLOCK - 1) / OBJ_BLOCK;
+    w->text.resize((size_t)w->nblocks);
+    w->len.assign((size_t)w->nblocks, 0);
+    // half of the cores: the caller's own work (the colour loop's launches, copies) runs beside these threads
+    const int nthreads = w->nblocks ? std::max(1, obj_threads(w->nblocks) / 2) : 0;
+    for (int t = 0; t < nthreads; ++t) w->pool.emplace_back([w]() { w->format_faces(); });
+    *writer = w;
+    return PIFU_OK;
+}
+
+extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts)
+{
+    PIFU_REQUIRE(writer, PIFU_ERR_INVALID, "pifu_obj_finish: null writer");
+    std::unique_ptr<ObjWriter> w((ObjWriter *)writer);
+    const bool args_ok = nverts >= 0 && ((verts && colors) || nverts == 0);
+    const int fd = w->fd;
+    std::atomic<bool> bad{false};
+    int64_t vbytes = 0;
+    if (args_ok && nverts > 0) {
+        const int64_t nblocks = (nverts + OBJ_BLOCK - 1) / OBJ_BLOCK;
+        std::unique_ptr<std::atomic<int64_t>[]> offs(new std::atomic<int64_t>[(size_t)nblocks + 1]);
+        for (int64_t i = 0; i <= nblocks; ++i) offs[i].store(i == 0 ? 0 : -1, std::memory_order_relaxed);
+        std::atomic<int64_t> next{0};
+        std::vector<std::thread> pool;
+        const int nthreads = obj_threads(nblocks);
+        for (int t = 0; t < nthreads; ++t) {
+            pool.emplace_back([&]() {
+                constexpr size_t FAST = (size_t)OBJ_BLOCK * OBJ_VERTEX_LINE + 64;
+                std::unique_ptr<char[]> own(new char[FAST]);               // uninitialised on purpose, re-used per block
+                std::unique_ptr<char[]> big;
+                for (;;) {
+                    const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+                    if (b >= nblocks) break;
+                    const int64_t lo = b * OBJ_BLOCK, hi = std::min(nverts, lo + OBJ_BLOCK);
+                    const size_t slow = count_slow_values(verts, colors, lo, hi);
+                    char *base = own.get();
+                    if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
+                    char *o = format_vertex_lines(base, verts, colors, lo, hi);
+                    int64_t off;
+                    while ((off = offs[b].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+                    const size_t n = (size_t)(o - base);
+                    offs[b + 1].store(off + (int64_t)n, std::memory_order_release);
+                    if (!write_all(fd, base, n, off)) bad.store(true);
+                    big.reset();
+                }
+            });
+        }
+        for (auto &th : pool) th.join();
+        vbytes = offs[nblocks].load();
+    }
+    for (auto &th : w->pool) th.join();
+    if (args_ok && w->nblocks) {
+        std::vector<int64_t> off((size_t)w->nblocks + 1, vbytes);
+        for (int64_t b = 0; b < w->nblocks; ++b) off[b + 1] = off[b] + (int64_t)w->len[b];
+        std::atomic<int64_t> next{0};
+        std::vector<std::thread> pool;
+        const int nthreads = obj_threads(w->nblocks);
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&]() {
+                for (;;) {
+                    const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+                    if (b >= w->nblocks) break;
+                    if (!write_all(fd, w->text[b].get(), w->len[b], off[b])) bad.store(true);
+                    w->text[b].reset();
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    if (close(fd) != 0) bad.store(true);
+    PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: bad argument");
+    PIFU_REQUIRE(!bad.load(), PIFU_ERR_INVALID, "pifu_obj_finish: write error on %s", w->path.c_str());
+    return PIFU_OK;
+}
+
 extern "C" int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                               const int32_t *faces, int64_t nfaces)
 {
@@ -428,65 +601,40 @@ extern "C" int pifu_write_obj(const char *path, const double *verts, const doubl
                  "pifu_write_obj: null argument");
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_write_obj: cannot open %s", path);
-    unsigned hw = std::thread::hardware_concurrency();
-    const int64_t total = nverts + nfaces;
-    // The lines are cut into blocks handed out in file order; a thread formats a block into its own (re-used, cache-resident)
-    // buffer, takes the block's file offset from its predecessor's (offset + length) - known as soon as the predecessor is
-    // formatted, before it is written - and writes the block at that offset.  No buffer of the size of the file, no serial
-    // write, and vertex / face blocks of different cost balance by themselves.
-    constexpr int64_t BLOCK = 16384;
-    const int64_t nblocks = (total + BLOCK - 1) / BLOCK;
-    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hw ? hw : 1u, 32u), nblocks));
+    // one pass: the vertex blocks, then the face blocks, handed out in file order; a thread formats a block into its own
+    // (re-used, cache-resident) buffer, takes the block's file offset from its predecessor's (offset + length) - known as
+    // soon as the predecessor is formatted - and writes the block at that offset
+    const int64_t vblocks = (nverts + OBJ_BLOCK - 1) / OBJ_BLOCK, fblocks = (nfaces + OBJ_BLOCK - 1) / OBJ_BLOCK;
+    const int64_t nblocks = vblocks + fblocks;
     std::unique_ptr<std::atomic<int64_t>[]> offs(new std::atomic<int64_t>[(size_t)nblocks + 1]);
     for (int64_t i = 0; i <= nblocks; ++i) offs[i].store(i == 0 ? 0 : -1, std::memory_order_relaxed);
     std::atomic<int64_t> next{0};
     std::atomic<bool> bad{false};
     std::vector<std::thread> pool;
+    const int nthreads = obj_threads(nblocks);
     for (int t = 0; t < nthreads; ++t) {
         pool.emplace_back([&]() {
-            constexpr size_t FAST = (size_t)BLOCK * 168 + 64;         // a block without out-of-range values
+            constexpr size_t FAST = (size_t)OBJ_BLOCK * OBJ_VERTEX_LINE + 64;
             std::unique_ptr<char[]> own(new char[FAST]);               // uninitialised on purpose
             std::unique_ptr<char[]> big;
             for (;;) {
                 const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
                 if (b >= nblocks) break;
-                const int64_t lo = b * BLOCK, hi = std::min(total, lo + BLOCK);
-                const int64_t nv_here = std::max<int64_t>(0, std::min(hi, nverts) - lo);
-                size_t slow = 0;      // values outside the fast formatter's range need up to SLOW_CHARS characters each
-                for (int64_t i = lo; i < lo + nv_here; ++i)
-                    for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
-                char *base = own.get();
-                if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
-                char *o = base;
-                for (int64_t i = lo; i < hi; ++i) {
-                    if (i < nverts) {
-                        const double *v = verts + 3 * i, *c = colors + 3 * i;
-                        *o++ = 'v';
-                        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
-                        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
-                        *o++ = '\n';
-                    } else {
-                        const int32_t *tr = faces + 3 * (i - nverts);
-                        const int idx[3] = {tr[0] + 1, tr[2] + 1, tr[1] + 1};
-                        *o++ = 'f';
-                        for (int k = 0; k < 3; ++k) {
-                            *o++ = ' ';
-                            if (idx[k] < 0) { *o++ = '-'; o = put_uint(o, (uint64_t)(-(int64_t)idx[k])); }
-                            else o = put_uint(o, (uint64_t)idx[k]);
-                        }
-                        *o++ = '\n';
-                    }
+                char *base = own.get(), *o;
+                if (b < vblocks) {
+                    const int64_t lo = b * OBJ_BLOCK, hi = std::min(nverts, lo + OBJ_BLOCK);
+                    const size_t slow = count_slow_values(verts, colors, lo, hi);
+                    if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
+                    o = format_vertex_lines(base, verts, colors, lo, hi);
+                } else {
+                    const int64_t lo = (b - vblocks) * OBJ_BLOCK, hi = std::min(nfaces, lo + OBJ_BLOCK);
+                    o = format_face_lines(base, faces, 3, 1, lo, hi);
                 }
                 int64_t off;
                 while ((off = offs[b].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
-                size_t left = (size_t)(o - base);
-                offs[b + 1].store(off + (int64_t)left, std::memory_order_release);
-                const char *src = base;
-                while (left) {
-                    const ssize_t w = pwrite(fd, src, left, (off_t)off);
-                    if (w <= 0) { bad.store(true); break; }
-                    src += w; off += w; left -= (size_t)w;
-                }
+                const size_t n = (size_t)(o - base);
+                offs[b + 1].store(off + (int64_t)n, std::memory_order_release);
+                if (!write_all(fd, base, n, off)) bad.store(true);
                 big.reset();
             }
         });

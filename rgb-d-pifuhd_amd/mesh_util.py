@@ -316,6 +316,37 @@ def eval_grid_octree(coords, eval_func, init_resolution=64, threshold=0.05, num_
     return sdf.cpu().numpy()
 
 
+class ObjFile:
+    """`save_obj_mesh_with_color` (`mesh_util.py:189-198`) in two steps: the face lines are formatted in the background from
+    the moment the triangles are known, `finish(verts, colors)` adds the vertex lines and writes the file."""
+
+    def __init__(self, mesh_path, faces):
+        f = np.asarray(faces)
+        if f.dtype != np.int32 or f.ndim != 2 or f.shape[1] != 3 or f.strides[0] % 4 or f.strides[1] % 4:
+            f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        self._faces = f                                  # kept alive until finish(): the worker threads read it
+        self._h = C.c_void_p()
+        _lib.call('pifu_obj_begin', str(mesh_path).encode(), f.ctypes.data_as(C.c_void_p), len(f), f.strides[0] // 4,
+                  f.strides[1] // 4, C.byref(self._h))
+
+    def finish(self, verts, colors):
+        v = np.ascontiguousarray(verts, dtype=np.float64)
+        c = np.ascontiguousarray(colors, dtype=np.float64)
+        h, self._h = self._h, None
+        try:
+            _lib.call('pifu_obj_finish', h, v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(v))
+        finally:
+            self._faces = None
+
+    def __del__(self):                                   # an abandoned writer (exception between the two steps)
+        if getattr(self, '_h', None):
+            try:
+                _lib.call('pifu_obj_finish', self._h, None, None, 0)
+            except Exception:
+                pass
+            self._h = None
+
+
 def save_obj_mesh_with_color(mesh_path, verts, faces, colors):
     """`save_obj_mesh_with_color` (`mesh_util.py:189-198`), native writer."""
     v = np.ascontiguousarray(verts, dtype=np.float64)

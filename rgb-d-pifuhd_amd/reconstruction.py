@@ -16,7 +16,7 @@ import torch
 
 from numpy.linalg import inv
 
-from .mesh_util import reconstruction, save_obj_mesh_with_color
+from .mesh_util import ObjFile, reconstruction, save_obj_mesh_with_color
 from .nets import index
 
 
@@ -100,6 +100,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh, use_octree=use_octree,
                                         num_samples=5000, sharded=sharded)
     t3 = mark()
+    obj = ObjFile(save_path, faces) if rank == 0 else None       # the face lines are formatted while the colours are computed
     verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
 
     spans = _normal_spans(len(verts))
@@ -125,8 +126,8 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     color[:color32.shape[0]] = color32.cpu().numpy()
     t4 = mark()
 
-    if rank == 0:
-        save_obj_mesh_with_color(save_path, verts, faces, color)
+    if obj is not None:
+        obj.finish(verts, color)                                  # save_obj_mesh_with_color (mesh_util.py:189-198)
     if png_thread is not None:
         png_thread.join()
     t5 = time.perf_counter()

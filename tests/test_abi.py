@@ -91,6 +91,15 @@ def test_obj_writer_host_only(lib, tmp_path):
     assert p.read_text() == O.obj_text(v, f, c)
     mesh_util.save_obj_mesh_with_color(str(p), v[:0], f[:0], c[:0])
     assert p.read_text() == ''
+    # the two-step writer gen_mesh uses (face lines formatted while the colours are still being computed): same bytes, also
+    # from the reversed view `reconstruction()` returns for a mirroring calib (no copy: strides go through the ABI)
+    want = O.obj_text(v, f[:, ::-1], c)
+    w = mesh_util.ObjFile(str(p), f[:, ::-1])
+    w.finish(v, c)
+    assert p.read_text() == want
+    w = mesh_util.ObjFile(str(p), f[:0])
+    w.finish(v[:0], c[:0])
+    assert p.read_text() == ''
 
 
 def test_checkpoint_io_roundtrip(tmp_path):
