@@ -215,3 +215,28 @@ def test_slab_marching_cubes_world3_matches_the_replicated_run(tmp_path):
             got = np.load(tmp_path / f'mc_r{r}.npz')
             assert np.array_equal(got[f'f{i}'], f) and np.array_equal(got[f'v{i}'].view(np.uint32), v.view(np.uint32)), (i, r)
             assert int(got['raised']) == 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_under_torchrun():
+    """The N > 1 form of bench.py, launched the way the driver launches it (`python -m torch.distributed.run --nproc-per-node
+    2 ... bench.py --gpus 2`), with both ranks sharing this box's one GPU over gloo (PIFU_BENCH_ONE_GPU: RCCL refuses two
+    ranks on one device): slab-sharded lattice with the all-gather inside the timed region, max-over-ranks timing, the
+    sharded gen_mesh of one subject and the independent subjects, ONE JSON line from rank 0.  A rehearsal, not a number."""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--res', '64',
+           '--genmesh-res', '64', '--batch-rows', '262144', '--no-split-precision', '--no-lean-pass', '--no-canonical']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PIFU_BENCH_ONE_GPU='1')
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['queries_per_step'] == 2 * 64 ** 3            # 64^3 per rank
+    gm = line['gen_mesh']
+    assert 'error' not in gm['one_subject_sharded'] and gm['one_subject_sharded']['n_verts'] > 0
+    assert 'error' not in gm['independent_subjects'] and gm['independent_subjects']['subjects'] == 2
