@@ -313,6 +313,46 @@ def test_depth_walk_equals_gemm_paths(mlp_norm):
     assert np.abs(w - p).max() < tol
 
 
+@pytest.mark.parametrize('dims', [[257, 1024, 256, 256, 128, 1], [257, 512, 1024, 256, 128, 1], [257, 256, 512, 256, 128, 1]])
+def test_depth_walk_with_other_layer_widths(dims):
+    """The depth walk for coarse MLPs whose layer 1 is 256 wide (one output per thread), 1024 wide (two slices of 512) and
+    whose layer 0 is 512 / 256 wide: same field as the GEMM form of layer 1 and as the per-point evaluation."""
+    import ctypes as C
+    from pifuhd_amd import _lib, config, nets, synth
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    oc = config.coarse_opt(mlp_dim=dims)
+    of = config.fine_opt(oc)
+    spec = {}
+    synth.mlp_keys('netG.mlp', oc.mlp_dim, oc.mlp_res_layers, oc.mlp_norm, spec)
+    synth.mlp_keys('mlp', of.mlp_dim, of.mlp_res_layers, of.mlp_norm, spec)
+    sd = synth.name_seeded_state_dict(spec, seed=4, mlp_std=0.16, perturb=True)
+    netG = nets.PIFuNetwNML(oc, 'orthogonal', 'cuda')
+    netMR = nets.PIFuMRNet(of, netG)
+    netG.eval()
+    netG._sd = {k[5:]: t.cuda() for k, t in sd.items() if k.startswith('netG.')}
+    netG._push_weights()
+    netMR._sd = {k: t.cuda() for k, t in sd.items() if not k.startswith('netG.')}
+    netMR._push_weights()
+    fc, ff = seeded_features(6)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib = np.ascontiguousarray(calib_tensor()[0].numpy())
+    cinv = np.ascontiguousarray(np.linalg.inv(calib.astype(np.float64)))
+    R0, R1, R2 = 12, 16, 64
+    res = (C.c_int32 * 3)(R0, R1, R2)
+    total = R0 * R1 * R2
+
+    def run(flags):
+        out = torch.empty(total, device='cuda')
+        _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  None, 0, total, 900, flags, _ptr(out), _stream_ptr(netMR.device))
+        return out.cpu().numpy()
+    w, g, p = run(_lib.Q_FULL_COARSE), run(_lib.Q_FULL_COARSE | _lib.Q_NO_DEPTH_WALK), run(_lib.Q_FULL_COARSE | _lib.Q_NO_COLUMN_SHARING)
+    assert np.abs(w - g).max() < 2e-5 and np.abs(w - p).max() < 2e-5
+    assert np.abs(w - g).max() > 0                           # the walk really ran
+    assert 0.02 < w.mean() < 0.98
+
+
 def test_full_size_lattice_properties():
     """BASELINE configs[1] at full size (dense 256^3, chunk 5000) through size-independent properties: the field does
     not depend on how many rows go into one batch of launches, a chunk-aligned slab evaluated on its own (the unit the
