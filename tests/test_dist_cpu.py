@@ -172,3 +172,22 @@ def test_slab_planes_cover_the_cell_layers_once():
             assert n >= 2 and z + n <= n0
             layers.extend(range(z, z + n - 1))
         assert layers == list(range(n0 - 1))
+
+
+def test_shard_chunks_at_config5_scale():
+    """BASELINE config 5: a 1024^3 lattice (2^30 points, 214 749 chunks of 5000) over 8 ranks - the shards are contiguous,
+    chunk-aligned, cover every point once, and only the last one is short - by fewer than 8 chunks of 26 844 (checked on the
+    boundaries only)."""
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.dist import shard_chunks
+    for total, chunk, ws in [(1024 ** 3, 5000, 8), (1024 ** 3, 5000, 7), (512 ** 3, 5000, 8), (1024 ** 3, 10000, 8)]:
+        end = 0
+        counts = []
+        for r in range(ws):
+            first, cnt, per = shard_chunks(total, chunk, ws, r)
+            assert first == end and first % chunk == 0
+            end = first + cnt
+            counts.append(cnt)
+        assert end == total
+        per = -(-(-(-total // chunk)) // ws)                     # chunks per rank, rounded up
+        assert max(counts) == per * chunk and min(counts) > (per - ws) * chunk      # only the last rank is short, by < ws chunks
