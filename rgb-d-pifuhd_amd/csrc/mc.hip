@@ -413,7 +413,7 @@ __global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_
 }
 
 struct McArena {
-    uint64_t *blk_verts, *blk_tris, *totals;
+    uint64_t *blk_verts, *blk_tris, *totals, *tile_sums;
     float *mm;
     uint8_t *brick;
     int32_t *edge_index;
@@ -423,7 +423,7 @@ struct McArena {
 
 constexpr int MM_BLOCKS = 1024;
 
-// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][brick map][edge_index 3*N int32]
+// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][scan scratch][brick map][edge_index 3*N int32]
 McArena carve(const Vol &v, char *base)
 {
     McArena a;
@@ -431,15 +431,17 @@ McArena carve(const Vol &v, char *base)
     a.nbricks = (int64_t)v.b0 * v.b1 * v.b2;
     const size_t scan_bytes = (size_t)round_up((a.nblocks + 1) * 8, 256);
     const size_t mm_bytes = (size_t)round_up((2 * MM_BLOCKS + 2) * 4, 256);
+    const size_t tile_bytes = (size_t)round_up((scan_tiles(a.nblocks) + 1) * 8, 256);
     const size_t brick_bytes = (size_t)round_up(a.nbricks, 256);
     const size_t edge_bytes = (size_t)3 * v.n0 * v.n1 * v.n2 * sizeof(int32_t);
     a.blk_verts = (uint64_t *)base;
     a.blk_tris = (uint64_t *)(base + scan_bytes);
     a.totals = (uint64_t *)(base + 2 * scan_bytes);
     a.mm = (float *)(base + 2 * scan_bytes + 256);
-    a.brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
-    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + brick_bytes);
-    a.bytes = 2 * scan_bytes + 256 + mm_bytes + brick_bytes + edge_bytes;
+    a.tile_sums = (uint64_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    a.brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes);
+    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes);
+    a.bytes = 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + edge_bytes;
     return a;
 }
 
@@ -468,8 +470,8 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
     hipLaunchKernelGGL(k_mc_minmax, dim3(MM_BLOCKS), dim3(256), 0, st, v, a.mm + 2);
     hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), MM_BLOCKS, a.mm);
     hipLaunchKernelGGL(k_mc_count, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, a.blk_verts, a.blk_tris);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, a.blk_verts, a.nblocks, a.totals);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, a.blk_tris, a.nblocks, a.totals + 1);
+    scan_u64(a.blk_verts, a.nblocks, a.totals, a.tile_sums, st);
+    scan_u64(a.blk_tris, a.nblocks, a.totals + 1, a.tile_sums, st);      // stream order: the scratch is free again
     // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
     rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
     if (rc) return rc;

@@ -148,12 +148,12 @@ int octree_select_impl(pifu_ctx *ctx, int R, int reso, const uint8_t *notproc, i
     const bool cached = !count_only && sel.valid && sel.R == R && sel.reso == reso && sel.notproc == notproc;
     if (!cached) {
         sel.valid = false;
-        int rc = pifu_ensure(ctx->misc, (size_t)(nblocks + 2) * sizeof(uint64_t));
+        int rc = pifu_ensure(ctx->misc, (size_t)(nblocks + 2 + scan_tiles(nblocks) + 1) * sizeof(uint64_t));
         if (rc) return rc;
         uint64_t *counts = (uint64_t *)ctx->misc.p;
         uint64_t *total = counts + nblocks;
         hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat, counts);
-        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, counts, nblocks, total);
+        scan_u64(counts, nblocks, total, counts + nblocks + 2, st);
         PIFU_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PIFU_HIP(hipStreamSynchronize(st));
         sel.n = (int64_t)(*(uint64_t *)ctx->pinned);

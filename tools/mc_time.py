@@ -1,6 +1,6 @@
 """Marching-cubes time on a smooth 512^3 volume (the analytic ellipsoid of SURVEY 8d: ~250 k vertices) and on a noisy one."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pifuhd_amd
 from pifuhd_amd import mesh_util
