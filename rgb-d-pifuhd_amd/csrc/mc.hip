@@ -184,6 +184,9 @@ struct Vol {
     // 8 x 8 x 8-cell bricks whose 9 x 9 x 9 nodes are not all on one side of the level (k_mc_bricks); null = classify every cell
     const uint8_t *brick;
     int b0, b1, b2;
+    // 1 for every group of 256 consecutive cells of the serial scan that touches such a brick (k_mc_groups); the three
+    // classification passes give a block MC_GPB groups and skip the others without touching their cells
+    const uint8_t *gflag;
     // slab mode (pifu_mc_slab_*): the volume holds node planes [zoff, zoff + n0) of a taller one.  Vertex ownership along
     // axis 0 and the axis-0 coordinate of the vertices refer to the tall volume; 0 for a whole volume
     int zoff;
@@ -293,21 +296,48 @@ __global__ void k_mc_bricks(const Vol v, uint8_t *brick)
     if (lane == 0) brick[b] = (any_pos && any_neg) ? 1 : 0;
 }
 
-// pass 1: block b covers cells [256 b, 256 b + 256) of the serial scan
-__global__ void k_mc_count(const Vol v, uint64_t *blk_verts, uint64_t *blk_tris)
+constexpr int MC_GPB = 16;      // groups of 256 cells per block of the classification passes
+
+// which groups of 256 consecutive cells can hold a surface cell at all: one thread per group walks its cells brick by brick
+__global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const int64_t lo = g * 256, hi = lo + 256 < v.ncells ? lo + 256 : v.ncells;
+    uint8_t any = 0;
+    for (int64_t c = lo; c < hi && !any;) {
+        const int x = (int)(c % v.c2), y = (int)((c / v.c2) % v.c1), z = (int)(c / ((int64_t)v.c2 * v.c1));
+        any = v.brick[((size_t)(z >> 3) * v.b1 + (y >> 3)) * v.b2 + (x >> 3)];
+        int step = 8 - (x & 7);                                  // to the next brick along x ...
+        if (step > v.c2 - x) step = v.c2 - x;                    // ... or the next row
+        c += step;
+    }
+    gflag[g] = any;
+}
+
+// pass 1: group g covers cells [256 g, 256 g + 256) of the serial scan; per-group (vertices, triangles) created
+__global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_verts, uint64_t *blk_tris)
 {
     __shared__ uint32_t sh[4];
-    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t packed = 0;
-    if (cell < v.ncells) {
-        CellInfo ci;
-        if (classify(v, cell, ci)) packed = (uint32_t)ci.nown | ((uint32_t)ci.nt << 16);
-    }
-    uint32_t tot;
-    block_exclusive_scan_256(packed, sh, &tot);
-    if (threadIdx.x == 0) {
-        blk_verts[blockIdx.x] = tot & 0xffffu;
-        blk_tris[blockIdx.x] = tot >> 16;
+    for (int gi = 0; gi < MC_GPB; ++gi) {
+        const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
+        if (group >= ngroups) break;
+        if (!v.gflag[group]) {                                   // block-uniform
+            if (threadIdx.x == 0) { blk_verts[group] = 0; blk_tris[group] = 0; }
+            continue;
+        }
+        const int64_t cell = group * 256 + threadIdx.x;
+        uint32_t packed = 0;
+        if (cell < v.ncells) {
+            CellInfo ci;
+            if (classify(v, cell, ci)) packed = (uint32_t)ci.nown | ((uint32_t)ci.nt << 16);
+        }
+        uint32_t tot;
+        block_exclusive_scan_256(packed, sh, &tot);
+        if (threadIdx.x == 0) {
+            blk_verts[group] = tot & 0xffffu;
+            blk_tris[group] = tot >> 16;
+        }
     }
 }
 
@@ -317,18 +347,23 @@ __device__ __forceinline__ size_t edge_slot(const Vol &v, int axis, int z, int y
 }
 
 // pass 2: vertex positions + per-grid-edge vertex index volume
-__global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, int64_t vert_base, float *verts, int32_t *edge_index)
+__global__ void k_mc_verts(const Vol v, int64_t ngroups, const uint64_t *blk_verts, int64_t vert_base, float *verts,
+                           int32_t *edge_index)
 {
     __shared__ uint32_t sh[4];
-    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int gi = 0; gi < MC_GPB; ++gi) {
+    const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
+    if (group >= ngroups) break;
+    if (!v.gflag[group]) continue;                               // block-uniform
+    const int64_t cell = group * 256 + threadIdx.x;
     CellInfo ci;
     bool active = false;
     if (cell < v.ncells) active = classify(v, cell, ci);
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan_256(active ? (uint32_t)ci.nown : 0u, sh, &tot);
-    if (!active || ci.nown == 0) return;
+    if (!active || ci.nown == 0) continue;
     // `verts` is this volume's own array (local numbering); the index volume holds numbers of the whole mesh
-    int64_t vid = (int64_t)blk_verts[blockIdx.x] + pre;
+    int64_t vid = (int64_t)blk_verts[group] + pre;
     const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
     unsigned seen = 0;
     for (int k = 0; k < 3 * ci.nt; ++k) {
@@ -366,22 +401,27 @@ __global__ void k_mc_verts(const Vol v, const uint64_t *blk_verts, int64_t vert_
             ++vid;
         }
     }
+  }
 }
 
 // pass 3: triangle indices ('descent' => the three indices of every triangle are reversed)
-__global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_t *blk_tris, int64_t vert_base,
+__global__ void k_mc_faces(const Vol v, int64_t ngroups, const uint64_t *blk_verts, const uint64_t *blk_tris, int64_t vert_base,
                            const int32_t *edge_index, int32_t *faces)
 {
     __shared__ uint32_t sh[4];
-    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int gi = 0; gi < MC_GPB; ++gi) {
+    const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
+    if (group >= ngroups) break;
+    if (!v.gflag[group]) continue;                               // block-uniform
+    const int64_t cell = group * 256 + threadIdx.x;
     CellInfo ci;
     bool active = false;
     if (cell < v.ncells) active = classify(v, cell, ci);
     uint32_t tot;
     const uint32_t pre = block_exclusive_scan_256(active ? ((uint32_t)ci.nown | ((uint32_t)ci.nt << 16)) : 0u, sh, &tot);
-    if (!active) return;
-    const int64_t vbase = vert_base + (int64_t)blk_verts[blockIdx.x] + (pre & 0xffffu);
-    int64_t f = (int64_t)blk_tris[blockIdx.x] + (pre >> 16);
+    if (!active) continue;
+    const int64_t vbase = vert_base + (int64_t)blk_verts[group] + (pre & 0xffffu);
+    int64_t f = (int64_t)blk_tris[group] + (pre >> 16);
     // index of the centre vertex = vbase + number of owned vertices first referenced before it
     const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
     int32_t centre = -1;
@@ -410,20 +450,21 @@ __global__ void k_mc_faces(const Vol v, const uint64_t *blk_verts, const uint64_
             faces[3 * (f + t) + (2 - k)] = vid;
         }
     }
+  }
 }
 
 struct McArena {
     uint64_t *blk_verts, *blk_tris, *totals, *tile_sums;
     float *mm;
-    uint8_t *brick;
+    uint8_t *brick, *gflag;
     int32_t *edge_index;
-    int64_t nblocks, nbricks;
+    int64_t nblocks, nbricks;      // nblocks = groups of 256 cells
     size_t bytes;
 };
 
 constexpr int MM_BLOCKS = 1024;
 
-// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][scan scratch][brick map][edge_index 3*N int32]
+// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][scan scratch][brick map][group flags][edge_index 3*N int32]
 McArena carve(const Vol &v, char *base)
 {
     McArena a;
@@ -439,16 +480,18 @@ McArena carve(const Vol &v, char *base)
     a.totals = (uint64_t *)(base + 2 * scan_bytes);
     a.mm = (float *)(base + 2 * scan_bytes + 256);
     a.tile_sums = (uint64_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
+    const size_t gflag_bytes = (size_t)round_up(a.nblocks, 256);
     a.brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes);
-    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes);
-    a.bytes = 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + edge_bytes;
+    a.gflag = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes);
+    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + gflag_bytes);
+    a.bytes = 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + gflag_bytes + edge_bytes;
     return a;
 }
 
 Vol make_vol(const void *volume, int dtype, int n0, int n1, int n2, double level, int zoff)
 {
     return Vol{volume, dtype, n0, n1, n2, n0 - 1, n1 - 1, n2 - 1, (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1), level, nullptr,
-               (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8, zoff};
+               (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8, nullptr, zoff};
 }
 
 // counting half, shared by the whole-volume and the slab entry points: totals and the value range on the host
@@ -469,7 +512,10 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
     v.brick = a.brick;
     hipLaunchKernelGGL(k_mc_minmax, dim3(MM_BLOCKS), dim3(256), 0, st, v, a.mm + 2);
     hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), MM_BLOCKS, a.mm);
-    hipLaunchKernelGGL(k_mc_count, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, a.blk_verts, a.blk_tris);
+    hipLaunchKernelGGL(k_mc_groups, dim3((unsigned)((a.nblocks + 255) / 256)), dim3(256), 0, st, v, a.nblocks, a.gflag);
+    v.gflag = a.gflag;
+    hipLaunchKernelGGL(k_mc_count, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks, a.blk_verts,
+                       a.blk_tris);
     scan_u64(a.blk_verts, a.nblocks, a.totals, a.tile_sums, st);
     scan_u64(a.blk_tris, a.nblocks, a.totals + 1, a.tile_sums, st);      // stream order: the scratch is free again
     // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
@@ -498,8 +544,9 @@ int mc_verts_impl(pifu_ctx *ctx, float *verts, int64_t vert_base, hipStream_t st
     Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
     const McArena a = carve(v, (char *)ctx->mc_arena.p);
     v.brick = a.brick;                                                        // built by the counting half for this volume
-    hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, (const uint64_t *)a.blk_verts, vert_base,
-                       verts, a.edge_index);
+    v.gflag = a.gflag;
+    hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks,
+                       (const uint64_t *)a.blk_verts, vert_base, verts, a.edge_index);
     m.verts_done = true;
     m.vert_base = vert_base;
     return PIFU_OK;
@@ -511,8 +558,9 @@ int mc_faces_impl(pifu_ctx *ctx, int32_t *faces, hipStream_t st)
     Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
     const McArena a = carve(v, (char *)ctx->mc_arena.p);
     v.brick = a.brick;
-    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)a.nblocks), dim3(256), 0, st, v, (const uint64_t *)a.blk_verts,
-                       (const uint64_t *)a.blk_tris, m.vert_base, (const int32_t *)a.edge_index, faces);
+    v.gflag = a.gflag;
+    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks,
+                       (const uint64_t *)a.blk_verts, (const uint64_t *)a.blk_tris, m.vert_base, (const int32_t *)a.edge_index, faces);
     return PIFU_OK;
 }
 
