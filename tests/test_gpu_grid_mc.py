@@ -536,3 +536,32 @@ def test_dense_grid_with_nontrivial_calibrations(golden_dir, tag):
     want_v = (np.matmul(tm[:3, :3], vr.T.astype(np.float32)) + tm[:3, 3:4]).T
     assert np.array_equal(verts, want_v)
     assert np.array_equal(faces, fr[:, ::-1] if np.linalg.det(tm[:3, :3]) < 0 else fr)
+
+
+def test_full_size_marching_cubes_properties(ctx):
+    """Size-independent properties at BASELINE's grid size (512^3), where the serial oracle is too slow to be the checker:
+    the mesh of a closed analytic body is ONE watertight component (every edge shared by exactly two faces:
+    `pifu_face_components`), its Euler characteristic is 2 (V - F / 2 = 2 for a closed triangle mesh of genus 0), every face
+    index is a valid vertex, the vertices lie within half a cell of the analytic surface, and a second run reproduces the
+    arrays bit for bit."""
+    from pifuhd_amd import _lib, mesh_util
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    R = 512
+    lin = torch.linspace(-1.0, 1.0 - 2.0 / R, R, device='cuda', dtype=torch.float64)
+    x, y, z = lin[:, None, None], lin[None, :, None], lin[None, None, :]
+    rad = torch.sqrt((0.9 * x) ** 2 + (0.55 * y) ** 2 + (1.5 * z) ** 2)
+    vol = torch.sigmoid((0.45 - rad) / 0.01)
+    del x, y, z, rad
+    v, f = mesh_util.marching_cubes_device(ctx, vol, 0.5)
+    V, F = len(v), len(f)
+    assert V > 200_000 and F % 2 == 0 and V - F // 2 == 2
+    assert int(f.min()) == 0 and int(f.max()) == V - 1
+    label = torch.empty(F, device='cuda', dtype=torch.int32)
+    open_edge = torch.empty(F, device='cuda', dtype=torch.uint8)
+    _lib.call('pifu_face_components', ctx.h, _ptr(f), F, _ptr(label), _ptr(open_edge), _stream_ptr(ctx.device))
+    assert int(open_edge.sum()) == 0 and int(label.max()) == 0
+    p = v.double() * (2.0 / R) - 1.0                        # array-axis order = (x, y, z) of the lattice above
+    r = torch.sqrt((0.9 * p[:, 0]) ** 2 + (0.55 * p[:, 1]) ** 2 + (1.5 * p[:, 2]) ** 2)
+    assert float((r - 0.45).abs().max()) < 1.5 * 1.5 * (2.0 / R)        # within a cell of the level set (largest axis scale 1.5)
+    v2, f2 = mesh_util.marching_cubes_device(ctx, vol, 0.5)
+    assert torch.equal(f, f2) and torch.equal(v.view(torch.int32), v2.view(torch.int32))
