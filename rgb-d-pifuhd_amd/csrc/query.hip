@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 // lab builds only (tools/lab): the predecessors of k_mlp_gemm_tri (bit-identity A/B) and the rejected schedules
 #include "gemm_predecessors.inc"
 #include "gemm_dma.inc"
+#include "gemm_wide32.inc"
 #ifdef PIFU_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
 #endif

@@ -2,7 +2,7 @@
 usage: python tools/ab_gemm.py <variant> [res]"""
 import hashlib, os, sys, time
 os.environ['PIFU_GEMM_VARIANT'] = sys.argv[1]
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools/lab'); import lab; lab.use()      # lab build: the PIFU_* switches live there
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tools', 'lab')); import lab; lab.use()      # lab build: the PIFU_* switches live there
 import torch
 import pifuhd_amd
 from pifuhd_amd import config, nets, synth, _lib, dist as pdist
