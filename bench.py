@@ -22,10 +22,15 @@ import ctypes as C
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL (and any sharing of device tensors between processes) needs dmabuf IPC handles on this pool: the host driver has no
+# legacy IPC mode, and without this setting hipIpcGetMemHandle fails with "invalid argument" as soon as two ranks meet.
+# Must be in the environment before the HIP runtime loads, i.e. before torch is imported.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 FLOP_PER_QUERY = 2916098            # coarse MLP 2,100,738 + fine MLP 815,360
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
@@ -43,6 +48,83 @@ def read_prof(_lib, h, which, reset=1):
 def reset_prof(_lib, h):
     for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC):
         _lib.call('pifu_profile_read', h, which, None, None, None, 1)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a FRESH child (`python -m torch.distributed.run`,
+    the command the driver itself uses) before torch or the GPU is touched in this process, let it write to this process's
+    stdout / stderr, and hand back its return code.  The elastic agent ends the other ranks when one of them fails, so a
+    failed rank cannot leave the rest waiting in a collective."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, cwd=ROOT).returncode
+
+
+def measured_mhz(clk0, clk1):
+    """Average shader clock between two `pifu_clock_probe` samples: shader-counter ticks per real-time tick (100 MHz), per
+    XCD that both probes sampled, median over the XCDs (an XCD whose counter was reset by power gating reads garbage and
+    is dropped).  s_memtime counts the clock the CUs actually ran at, power management included."""
+    mhz = [100.0 * (clk1[2 * x] - clk0[2 * x]) / (clk1[2 * x + 1] - clk0[2 * x + 1])
+           for x in range(8) if clk0[2 * x + 1] and clk1[2 * x + 1] > clk0[2 * x + 1]]
+    mhz = sorted(m for m in mhz if 100.0 < m < 4000.0)
+    return mhz[len(mhz) // 2] if mhz else None
+
+
+def rccl_choices(path):
+    """What RCCL logged (NCCL_DEBUG=INFO, subsystems INIT / GRAPH / TUNING) about the communicator of this rank: how many
+    channels, ring or tree, which transport each channel uses (P2P/IPC over xGMI, SHM, ...), and the algorithm / protocol
+    lines of the tuning subsystem where the build emits them.  One short summary per rank, taken after the warm-up
+    collectives have run."""
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    keep = re.compile(r'(Algo|algorithm|[Pp]roto|Ring \d|Trees|Channel \d+/\d+ *:|via |nChannels|Pattern|XGMI|P2P|comm 0x.*nranks)')
+    lines, seen = [], set()
+    with open(path, errors='replace') as fh:
+        for ln in fh:
+            if not keep.search(ln):
+                continue
+            txt = ln.split('NCCL INFO', 1)[-1].strip()
+            key = re.sub(r'\d+', '#', txt)[:60]          # one example per kind of line
+            if key in seen:
+                continue
+            seen.add(key)
+            lines.append(txt[:200])
+    text = ' '.join(lines)
+    return {'lines': lines[:24], 'mentions_ring': 'Ring' in text, 'mentions_tree': 'Tree' in text,
+            'transports': sorted(set(re.findall(r'via ([A-Za-z0-9/_]+)', text)))}
+
+
+def smoother_subject(args, dev, data):
+    """The second bench subject: the same image and architecture with the MLP weights drawn at torch's stock scale (std
+    0.02 instead of the 0.16 that gives the headline subject its rough, multi-million-vertex surface).  Fewer points survive
+    the octree and fewer vertices need normals - the other end of what a reconstruction can look like.  Returns netMR with
+    both filters run and the 0.5 level set centred in the volume."""
+    from pifuhd_amd import config, nets, synth
+    oc = config.coarse_opt(in_image_channels=args.image_channels)
+    of = config.fine_opt(oc)
+    sd2 = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.02)
+    _, netMR2 = nets.build_nets(oc, of, sd2, dev)
+    netMR2.filter_global(data['img_512'].to(dev))
+    netMR2.filter_local(data['img'].to(dev)[:, None])
+    synth.calibrate_occupancy_bias(netMR2, data['calib'], sd2, 0.3)
+    return netMR2
+
+
+def mesh_digest(verts, faces, color):
+    """56 bits of the sha256 over a mesh's arrays, as a non-negative int64 (for an all-reduce across ranks)."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a in (verts, faces, color):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return int.from_bytes(h.digest()[:7], 'little')
 
 
 def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
@@ -95,6 +177,43 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3)}
         else:
             res['independent_subjects'] = {'error': err or 'failed on another rank'}
+        # (c) BASELINE configs[4]: ONE subject at 1024^3, octree levels sharded by chunk ranges with one all-gather per level,
+        # marching cubes over one axis-0 slab per rank (dist.SLAB_MC_MIN_RESOLUTION = 1024 is reached), colour loop sharded
+        # by calc_normal calls.  The smoother subject (MLP weights at torch's stock scale): its surface is what a trained
+        # net's looks like, and its mesh stays in the millions of vertices at this resolution.
+        if args.config5_res > 0:
+            timings, err, t_tot, sha = {}, None, float('inf'), 0
+            try:
+                net5 = smoother_subject(args, dev, data)
+                fence()
+                recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'warm5_{rank}.obj'), sharded=True)
+                fence()
+                t0 = time.perf_counter()
+                mesh = recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'mesh5_{rank}.obj'), timings=timings,
+                                      sharded=True)
+                fence()
+                t_tot = time.perf_counter() - t0
+                sha = mesh_digest(*mesh)
+                del net5
+            except Exception as e:
+                err = repr(e)
+            red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
+            # every rank must hold the same mesh: max(sha) == min(sha) over the ranks (56 bits of the sha256 of vertices,
+            # faces and colours)
+            t = torch.tensor([sha, -sha], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if err is None and red[0] != float('inf'):
+                from pifuhd_amd import dist as pdist
+                res['config5_1024'] = {
+                    'resolution': args.config5_res, 'subject': 'smoother (mlp_weight_std 0.02)', 'total_s': round(red[0], 4),
+                    **{k: round(v, 4) for k, v in zip(keys, red[1:])}, 'n_verts': timings.get('n_verts'),
+                    'n_faces': timings.get('n_faces'),
+                    'marching_cubes': 'one axis-0 slab per rank' if args.config5_res >= pdist.SLAB_MC_MIN_RESOLUTION
+                    else 'replicated (below dist.SLAB_MC_MIN_RESOLUTION)',
+                    'mesh_identical_on_all_ranks': bool(int(t[0]) == -int(t[1])), 'mesh_sha256_56bit': '%014x' % int(t[0])}
+                log(f"config 5: gen_mesh {args.config5_res}^3 sharded over {world} ranks: {red[0]:.3f} s, {timings.get('n_verts')} vertices")
+            else:
+                res['config5_1024'] = {'error': err or 'failed on another rank'}
     return res
 
 
@@ -115,12 +234,16 @@ def main():
     ap.add_argument('--dist-selftest', action='store_true',
                     help='functional check, never a measurement: initialise the process group (backend nccl = RCCL) even with ONE '
                          'rank and run every collective of the sharded path (all-gather of the field, of the colours, barrier)')
+    ap.add_argument('--no-chunk100k', action='store_true', help='skip the extra pass in 100 000-point chunks')
     ap.add_argument('--no-canonical', action='store_true', help='skip the extra canonical per-point pass (no column sharing)')
     ap.add_argument('--canonical-steps', type=int, default=2)
     ap.add_argument('--no-cpu-genmesh', action='store_true', help='skip the CPU (oracle) gen_mesh baseline at --cpu-genmesh-res')
     ap.add_argument('--cpu-genmesh-res', type=int, default=128)
+    ap.add_argument('--cpu-genmesh-res2', type=int, default=256, help='second CPU gen_mesh baseline, run when the first took < 40 s')
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra bf16x3 / fp16x3 measurements')
     ap.add_argument('--genmesh-res', type=int, default=512)
+    ap.add_argument('--config5-res', type=int, default=1024,
+                    help='resolution of the BASELINE configs[4] leg (one subject, sharded over all ranks at N > 1; 0 = skip)')
     ap.add_argument('--no-smooth-genmesh', action='store_true', help='skip the second gen_mesh subject (stock-scale MLP weights)')
     ap.add_argument('--image-channels', type=int, default=6, choices=[3, 6],
                     help='6 = RGB-D input (RGB || depth, BASELINE config 2; SURVEY C-7), 3 = RGB as the reference is committed')
@@ -132,6 +255,8 @@ def main():
     ap.add_argument('--no-column-sharing', action='store_true',
                     help='evaluate every lattice point independently (the canonical 2 916 098 FLOP per query)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # plain `python bench.py --gpus N`: start the ranks; nothing has touched the GPU yet
 
     import numpy as np
     import torch
@@ -151,6 +276,7 @@ def main():
     # PIFU_BENCH_ONE_GPU=1 is a functional test hook: all ranks share cuda:0 and talk over gloo (RCCL refuses two ranks
     # on one device), so the N > 1 code path can be exercised on a single-GPU box; never a measurement
     one_gpu_test = os.environ.get('PIFU_BENCH_ONE_GPU') == '1'
+    rccl_log = None
     dev = torch.device('cuda', 0 if one_gpu_test else local_rank)
     torch.cuda.set_device(dev)
     if world > 1 or args.dist_selftest:
@@ -158,10 +284,18 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
+        import datetime
         if one_gpu_test:
-            dist.init_process_group('gloo')
+            dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=20))
         else:
-            dist.init_process_group('nccl', device_id=dev)
+            # RCCL's own account of what it built (rings / trees, transport per channel, and - where the build logs it - the
+            # algorithm and protocol it picks per collective): written by every rank to its own file, summarised once below
+            rccl_log = os.path.join(tempfile.gettempdir(), f'pifu_rccl_{os.getpid()}_r{rank}.log')
+            os.environ.setdefault('NCCL_DEBUG', 'INFO')
+            os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+            os.environ.setdefault('NCCL_DEBUG_FILE', rccl_log)
+            # a rank that dies takes the job down (torch.distributed.run ends its siblings); a rank that hangs is cut by this
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=20))
         if args.dist_selftest:
             pdist.ALWAYS_COLLECTIVE = True
 
@@ -211,10 +345,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if grouped and os.environ.get('PIFU_BENCH_FAIL_RANK') == str(rank):
+        raise RuntimeError('test hook: this rank fails before its first collective')      # tests/test_gpu_dist.py
     for _ in range(args.warmup):
         step()
     fence()
     log('warm-up done')
+    rccl_summary = rccl_choices(os.environ.get('NCCL_DEBUG_FILE') if rccl_log else None)
+    if rccl_summary:
+        log('RCCL: ' + ' | '.join(rccl_summary['lines'][:6]))
     reset_prof(_lib, h)
     _lib.call('pifu_profile_enable', h, 1)
 
@@ -234,10 +373,7 @@ def main():
     log(f'timed region done: {elapsed:.3f} s')
     # average shader clock over the timed region: shader-counter ticks per real-time tick (100 MHz), per XCD that
     # both probes sampled; s_memtime counts the clock the CUs actually ran at (power management included)
-    mhz = [100.0 * (clk1[2 * x] - clk0[2 * x]) / (clk1[2 * x + 1] - clk0[2 * x + 1])
-           for x in range(8) if clk0[2 * x + 1] and clk1[2 * x + 1] > clk0[2 * x + 1]]
-    mhz = sorted(m for m in mhz if 100.0 < m < 4000.0)      # an XCD whose counter was reset by power gating reads garbage: dropped
-    eff_mhz = mhz[len(mhz) // 2] if mhz else None            # median over the XCDs
+    eff_mhz = measured_mhz(clk0, clk1)
     _lib.call('pifu_profile_enable', h, 0)
     g_ms, g_n, g_fl = read_prof(_lib, h, _lib.PROF_GEMM)
     gemm_ms, gemm_n, gemm_flops = C.c_double(g_ms), C.c_int64(g_n), C.c_double(g_fl)
@@ -312,11 +448,14 @@ def main():
             fence()
             reset_prof(_lib, h)
             _lib.call('pifu_profile_enable', h, 1)
+            ck0 = clock_probe()
+            fence()
             c0 = time.perf_counter()
             for _ in range(args.canonical_steps):
                 field_c = pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, cflags)
             fence()
             c_el = time.perf_counter() - c0
+            c_mhz = measured_mhz(ck0, clock_probe())
             _lib.call('pifu_profile_enable', h, 0)
             cg_ms, cg_n, cg_fl = read_prof(_lib, h, _lib.PROF_GEMM)
             cs_ms, cs_n, cs_by = read_prof(_lib, h, _lib.PROF_SAMPLER)
@@ -329,7 +468,9 @@ def main():
                 'whole_path_tflops': round(c_val * 1e6 * FLOP_PER_QUERY / 1e12, 2),
                 'whole_path_frac_of_fp32_matrix_peak': round(c_val * 1e6 * FLOP_PER_QUERY / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                 'gemm_roofline': {'kernel': 'k_mlp_gemm_tri', 'achieved': round(c_gemm, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
-                                  'unit': 'TFLOP/s', 'frac': round(c_gemm / PEAK_FP32_MATRIX_TFLOPS, 4), 'launches': cg_n},
+                                  'unit': 'TFLOP/s', 'frac': round(c_gemm / PEAK_FP32_MATRIX_TFLOPS, 4), 'launches': cg_n,
+                                  'shader_clock_mhz_measured': round(c_mhz, 1) if c_mhz else None,
+                                  'frac_at_measured_clock': round(c_gemm / (PEAK_FP32_MATRIX_TFLOPS * c_mhz / 2400.0), 4) if c_mhz else None},
                 'max_abs_diff_vs_headline_field': float((field_c - field).abs().max().item())}
             log(f"canonical per-point path: {c_val:.1f} Mq/s, GEMM {c_gemm:.1f} TFLOP/s")
             if cs_ms > 0:
@@ -378,6 +519,30 @@ def main():
             log(f"without the unread coarse tail: {out['without_unread_coarse_tail']['value']} Mq/s")
         except Exception as e:
             out['without_unread_coarse_tail'] = {'error': repr(e)}
+
+    # ---- the same lattice in the 100 000-point query() calls of the image-coloured variants (`reconstruction.py:108,160`:
+    # gen_mesh_imgColor / _plus pass num_samples=100000; GroupNorm then spans 100 000 points, so it is a different field)
+    if world == 1 and not args.no_chunk100k:
+        try:
+            pdist.eval_lattice_sharded(netMR, calib, res, 100000, flags)
+            fence()
+            reset_prof(_lib, h)
+            _lib.call('pifu_profile_enable', h, 1)
+            k0 = time.perf_counter()
+            for _ in range(args.steps):
+                pdist.eval_lattice_sharded(netMR, calib, res, 100000, flags)
+            fence()
+            k_el = time.perf_counter() - k0
+            _lib.call('pifu_profile_enable', h, 0)
+            kg_ms, kg_n, kg_fl = read_prof(_lib, h, _lib.PROF_GEMM)
+            out['chunk_100000'] = {'value': round(total * args.steps / k_el / 1e6, 3), 'unit': 'Mqueries/s',
+                                   'ms_per_step': round(k_el / max(args.steps, 1) * 1e3, 3), 'chunk': 100000,
+                                   'gemm_algorithmic_tflops': round(kg_fl / (kg_ms * 1e-3) / 1e12, 2) if kg_ms > 0 else None}
+            log(f"chunk 100000: {out['chunk_100000']['value']} Mq/s")
+        except Exception as e:
+            out['chunk_100000'] = {'error': repr(e)}
+        finally:
+            _lib.call('pifu_profile_enable', h, 0)
 
     # ---- opt-in split precision on the 16-bit matrix cores (bf16 x 3, fp16 x 3): reported beside the headline, never as `value`
     split_fields = {}
@@ -510,11 +675,7 @@ def main():
             # what config 3 can look like.  Reported beside the headline subject, never instead of it.
             if not args.no_smooth_genmesh and 'error' not in out['gen_mesh']:
                 try:
-                    sd2 = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.02)
-                    netG2, netMR2 = nets.build_nets(oc, of, sd2, dev)
-                    netMR2.filter_global(data['img_512'].to(dev))
-                    netMR2.filter_local(data['img'].to(dev)[:, None])
-                    synth.calibrate_occupancy_bias(netMR2, calib, sd2, 0.3)
+                    netMR2 = smoother_subject(args, dev, data)
                     # warm-up at the timed size: this context's workspaces grow here, not inside the timed call
                     recon.gen_mesh(args.genmesh_res, netMR2, dev, data, os.path.join(td, 'warm2.obj'))
                     t2 = {}
@@ -522,7 +683,21 @@ def main():
                     out['gen_mesh']['smoother_subject'] = {
                         'mlp_weight_std': 0.02, **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t2.items()}}
                     log(f"gen_mesh, smoother subject: {t2.get('total_s'):.3f} s, {t2.get('n_verts')} vertices")
-                    del netG2, netMR2
+                    # BASELINE configs[4]'s grid on this ONE GPU (the N > 1 line shards the same call over the ranks)
+                    if args.config5_res > 0:
+                        try:
+                            recon.gen_mesh(args.config5_res, netMR2, dev, data, os.path.join(td, 'warm5.obj'))
+                            t5 = {}
+                            m5 = recon.gen_mesh(args.config5_res, netMR2, dev, data, os.path.join(td, 'mesh5.obj'), timings=t5)
+                            out['gen_mesh']['config5_1024'] = {
+                                'resolution': args.config5_res, 'subject': 'smoother (mlp_weight_std 0.02)', 'n_gpus': 1,
+                                **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t5.items()},
+                                'mesh_sha256_56bit': '%014x' % mesh_digest(*m5)}
+                            log(f"config 5 grid on one GPU: gen_mesh {args.config5_res}^3 {t5.get('total_s'):.3f} s, {t5.get('n_verts')} vertices")
+                            del m5
+                        except Exception as e:
+                            out['gen_mesh']['config5_1024'] = {'error': repr(e)}
+                    del netMR2
                 except Exception as e:
                     out['gen_mesh']['smoother_subject'] = {'error': repr(e)}
 
@@ -531,22 +706,22 @@ def main():
             # with the GPU run at the SAME resolution beside it.  The encoders are left out on the CPU side (minutes there):
             # the oracle uses the feature maps of the GPU filter pass, which the sample text says.
             if not args.no_cpu_genmesh and not args.no_cpu_baseline:
-                try:
-                    from oracle import pifu_oracle as O
-                    Rc = args.cpu_genmesh_res
-                    ncores = min(os.cpu_count() or 1, args.cpu_threads)
-                    torch.set_num_threads(ncores)
-                    ref = O.OracleNets(sd, oc, of, fine_training=True)
-                    ref.feat_coarse = netG.im_feat_list[-1].cpu()
-                    ref.feat_fine = netMR.im_feat_list[-1].cpu()
-                    calib_np = calib[0].numpy().astype(np.float64)
+                from oracle import pifu_oracle as O
+                ncores = min(os.cpu_count() or 1, args.cpu_threads)
+                torch.set_num_threads(ncores)
+                ref = O.OracleNets(sd, oc, of, fine_training=True)
+                ref.feat_coarse = netG.im_feat_list[-1].cpu()
+                ref.feat_fine = netMR.im_feat_list[-1].cpu()
+                calib_np = calib[0].numpy().astype(np.float64)
 
-                    def field(pts):
-                        with torch.no_grad():
-                            return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib)[0, 0].numpy()
+                def oracle_field(pts):
+                    with torch.no_grad():
+                        return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib)[0, 0].numpy()
+
+                def cpu_gen_mesh(Rc):
                     stats = []
                     c0 = time.perf_counter()
-                    sdf_c = O.eval_grid_octree(Rc, np.linalg.inv(calib_np), field, 5000, stats=stats)
+                    sdf_c = O.eval_grid_octree(Rc, np.linalg.inv(calib_np), oracle_field, 5000, stats=stats)
                     c1 = time.perf_counter()
                     cv, cf = O.marching_cubes_lewiner(sdf_c, 0.5)
                     c2 = time.perf_counter()
@@ -566,7 +741,11 @@ def main():
                     normals_s = (c3 - c2) * (len(cv) / max(done_v, 1))          # extrapolated when the loop was cut short
                     gt = {}
                     recon.gen_mesh(Rc, netMR, dev, data, os.path.join(td, 'same_res.obj'), timings=gt)
-                    out['cpu_baseline_gen_mesh'] = {
+                    # the composition on the device against the composition on the host: the float64 SDF of the whole
+                    # multi-level octree (network field), the points each evaluated, and the mesh
+                    sdf_g, n_gpu = mesh_util.eval_grid_device(netMR, calib, Rc, 5000, True)
+                    gv, gf = mesh_util.marching_cubes_device(netMR._ctx, sdf_g, 0.5)
+                    res_c = {
                         'resolution': Rc, 'kind': 'port', 'cores': ncores, 'unit': 's',
                         'value': round((c1 - c0) + (c2 - c1) + normals_s, 3),
                         'reconstruction_s': round(c2 - c0, 3), 'grid_eval_s': round(c1 - c0, 3), 'marching_cubes_s': round(c2 - c1, 3),
@@ -581,14 +760,29 @@ def main():
                                                 'reconstruction_s': round(gt.get('reconstruction_s', float('nan')), 4),
                                                 'normals_s': round(gt.get('normals_s', float('nan')), 4),
                                                 'obj_s': round(gt.get('obj_s', float('nan')), 4),
-                                                'n_verts': gt.get('n_verts'), 'n_faces': gt.get('n_faces')}}
-                    log(f"cpu gen_mesh baseline at {Rc}^3: {out['cpu_baseline_gen_mesh']['value']} s; GPU {gt.get('total_s'):.3f} s")
+                                                'n_verts': gt.get('n_verts'), 'n_faces': gt.get('n_faces'),
+                                                'points_evaluated': int(n_gpu),
+                                                'max_abs_diff_sdf': float(np.abs(sdf_g.cpu().numpy() - sdf_c).max()),
+                                                'same_points_evaluated': bool(int(n_gpu) == int(sum(n for _, n in stats))),
+                                                'mesh_size_equal': bool(len(gv) == len(cv) and len(gf) == len(cf))}}
+                    log(f"cpu gen_mesh baseline at {Rc}^3: {res_c['value']} s; GPU {gt.get('total_s'):.3f} s; "
+                        f"max |sdf_gpu - sdf_oracle| = {res_c['gpu_same_resolution']['max_abs_diff_sdf']:.2e}")
+                    return res_c, c3 - c0
+                try:
+                    out['cpu_baseline_gen_mesh'], spent = cpu_gen_mesh(args.cpu_genmesh_res)
+                    # BASELINE.md section 3 plans 64^3 / 256^3 / 512^3: the next size up when the host got through this one
+                    # quickly enough (8x the lattice, ~4x the octree's points)
+                    if spent < 40.0 and args.cpu_genmesh_res2 > args.cpu_genmesh_res:
+                        out['cpu_baseline_gen_mesh_%d' % args.cpu_genmesh_res2], _ = cpu_gen_mesh(args.cpu_genmesh_res2)
                 except Exception as e:
-                    out['cpu_baseline_gen_mesh'] = {'error': repr(e)}
+                    out.setdefault('cpu_baseline_gen_mesh', {'error': repr(e)})
+                    out['cpu_baseline_gen_mesh_error'] = repr(e)
     if secondary:
         out['roofline_secondary'] = secondary
     if multi is not None:
         out['gen_mesh'] = multi
+    if rccl_summary:
+        out['rccl'] = rccl_summary
     if args.dist_selftest:
         out['dist_selftest'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                 'collectives': 'all_gather_into_tensor (field, colours), all_reduce(MAX), barrier',

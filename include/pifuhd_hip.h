@@ -265,10 +265,12 @@ int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream stream);
 int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                    const int32_t *faces, int64_t nfaces);
 /* The same file in two calls, for callers that know the triangles before the vertex colours (gen_mesh: marching cubes, then
- * the colour loop, reconstruction.py:56-72): pifu_obj_begin opens the file and starts formatting the face lines on worker
- * threads (faces: HOST int32, triangle i at faces[i * row_stride + k * col_stride], k = 0..2 - a reversed view such as
- * faces[:, ::-1] needs no copy; it must stay alive until pifu_obj_finish); pifu_obj_finish formats the vertex lines, writes
- * vertices then faces, closes the file and frees the writer (also when it returns an error). */
+ * the colour loop, reconstruction.py:56-72): pifu_obj_begin starts formatting the face lines on worker threads, in memory
+ * (faces: HOST int32, triangle i at faces[i * row_stride + k * col_stride], k = 0..2 - a reversed view such as
+ * faces[:, ::-1] needs no copy; it must stay alive until pifu_obj_finish); pifu_obj_finish creates the file, formats the
+ * vertex lines, writes vertices then faces, closes the file and frees the writer (also when it returns an error).
+ * nverts < 0 abandons the writer: the workers are joined, nothing is created or truncated - a run that fails between the
+ * two calls leaves `path` as it was, like the reference, which only writes once the colours exist. */
 int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride, void **writer);
 int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts);
 

@@ -131,7 +131,7 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
         for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(ctx->mlp[L].layer[i]);
         if (ctx->feat[L].nhwc) (void)hipFree(ctx->feat[L].nhwc);
     }
-    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc, &ctx->col_arena};
+    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc, &ctx->col_arena, &ctx->sel_counts};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int L = 0; L < 2; ++L)
@@ -516,10 +516,10 @@ extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nf
                               void **writer)
 {
     PIFU_REQUIRE(path && writer && (faces || nfaces == 0) && nfaces >= 0, PIFU_ERR_INVALID, "pifu_obj_begin: bad argument");
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_obj_begin: cannot open %s", path);
+    // the file itself is created by pifu_obj_finish: like the reference's writer (mesh_util.py:189-198, called once the colours
+    // exist) a run that fails between the two steps leaves whatever was at `path` untouched
     ObjWriter *w = new ObjWriter();
-    w->fd = fd; w->path = path; w->faces = faces; w->nfaces = nfaces; w->row_stride = row_stride; w->col_stride = col_stride;
+    w->path = path; w->faces = faces; w->nfaces = nfaces; w->row_stride = row_stride; w->col_stride = col_stride;
     w->nblocks = (nfaces + OBJ_BLOCK - 1) / OBJ_BLOCK;
     w->text.resize((size_t)w->nblocks);
     w->len.assign((size_t)w->nblocks, 0);
@@ -534,8 +534,17 @@ extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *
 {
     PIFU_REQUIRE(writer, PIFU_ERR_INVALID, "pifu_obj_finish: null writer");
     std::unique_ptr<ObjWriter> w((ObjWriter *)writer);
-    const bool args_ok = nverts >= 0 && ((verts && colors) || nverts == 0);
-    const int fd = w->fd;
+    if (nverts < 0) {                                   // abandon: wait for the face formatters, write nothing
+        for (auto &th : w->pool) th.join();
+        return PIFU_OK;
+    }
+    const bool args_ok = (verts && colors) || nverts == 0;
+    const int fd = args_ok ? open(w->path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666) : -1;
+    if (fd < 0) {
+        for (auto &th : w->pool) th.join();
+        PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: bad argument");
+        PIFU_REQUIRE(false, PIFU_ERR_INVALID, "pifu_obj_finish: cannot open %s", w->path.c_str());
+    }
     std::atomic<bool> bad{false};
     int64_t vbytes = 0;
     if (args_ok && nverts > 0) {
@@ -589,7 +598,6 @@ extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *
         for (auto &th : pool) th.join();
     }
     if (close(fd) != 0) bad.store(true);
-    PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: bad argument");
     PIFU_REQUIRE(!bad.load(), PIFU_ERR_INVALID, "pifu_obj_finish: write error on %s", w->path.c_str());
     return PIFU_OK;
 }

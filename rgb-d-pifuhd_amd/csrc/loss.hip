@@ -72,13 +72,12 @@ extern "C" int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, 
     PIFU_REQUIRE(ctx && pred && gt && out, PIFU_ERR_INVALID, "pifu_bce_loss: null argument");
     PIFU_REQUIRE(batch > 0 && n > 0, PIFU_ERR_INVALID, "pifu_bce_loss: empty input (the reference's mean() would be nan)");
     PIFU_HIP(hipSetDevice(ctx->device));
-    ctx->sel.valid = false;                  // the scratch below is shared with the octree level counts
     int rc = pifu_ensure(ctx->misc, LOSS_BLOCKS * sizeof(double));
     if (rc) return rc;
     BceArgs a{};
     a.pred = pred; a.gt = gt; a.gamma = gamma; a.w = w; a.n = n; a.total = (int64_t)batch * n;
     a.fixed_gamma = fixed_gamma; a.brock = brock != 0; a.w_full = w_per_element != 0;
-    a.partial = reinterpret_cast<double *>(ctx->misc.p);      // stream-ordered scratch shared with the octree scans
+    a.partial = reinterpret_cast<double *>(ctx->misc.p);      // stream-ordered scratch
     a.out = out;
     const int nblocks = (int)((a.total + 1023) / 1024 < LOSS_BLOCKS ? (a.total + 1023) / 1024 : LOSS_BLOCKS);
     hipStream_t st = (hipStream_t)stream;

@@ -44,7 +44,7 @@ __global__ void k_oct_count(const uint8_t *notproc, int R, int reso, int nl, int
 }
 
 __global__ void k_oct_scatter_index(const uint8_t *notproc, int R, int reso, int nl, int64_t nlat,
-                                    const uint64_t *block_offsets, int64_t *index_out)
+                                    const uint64_t *block_offsets, int64_t *index_out, int64_t cap)
 {
     __shared__ uint32_t sh[4];
     const int64_t base = (int64_t)blockIdx.x * SEL_TILE;
@@ -59,7 +59,7 @@ __global__ void k_oct_scatter_index(const uint8_t *notproc, int R, int reso, int
         }
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan_256(flag, sh, &tot);
-        if (flag) index_out[run + pre] = flat;
+        if (flag && (int64_t)(run + pre) < cap) index_out[run + pre] = flat;      // never past the caller's buffer
         run += tot;
     }
 }
@@ -134,10 +134,11 @@ __global__ void k_f32_to_f64(const float *src, double *dst, int64_t n)
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-// One level's test points.  Counting pass: per-block counts + scan into ctx->misc, ONE host synchronisation to return the
-// total (the caller sizes its index buffer from it).  Fill pass: ordered compaction from those block counts - when it follows
-// the counting pass of the same level directly (the normal call pattern) it launches the scatter kernel only, without a
-// second count or synchronisation; otherwise it recounts first.
+// One level's test points.  Both passes run the counting kernel + scan on the stream into the context's own `sel_counts`
+// buffer (nothing else writes there), so the scatter always works from offsets computed from the mask as it is NOW; the
+// scatter itself is bounded by `cap`.  What the counting pass keeps for the fill pass of the same level (the normal call
+// pattern: count, allocate, fill) is only the TOTAL it already brought to the host - one host synchronisation per level
+// instead of two.  The remembered total is dropped by every entry point that changes a mask (begin, commit).
 int octree_select_impl(pifu_ctx *ctx, int R, int reso, const uint8_t *notproc, int64_t *index_out, int64_t cap,
                        int64_t *count_host, bool count_only, hipStream_t st)
 {
@@ -145,29 +146,31 @@ int octree_select_impl(pifu_ctx *ctx, int R, int reso, const uint8_t *notproc, i
     const int64_t nlat = (int64_t)nl * nl * nl;
     const int64_t nblocks = (nlat + SEL_TILE - 1) / SEL_TILE;
     pifu_ctx::SelState &sel = ctx->sel;
-    const bool cached = !count_only && sel.valid && sel.R == R && sel.reso == reso && sel.notproc == notproc;
-    if (!cached) {
-        sel.valid = false;
-        int rc = pifu_ensure(ctx->misc, (size_t)(nblocks + 2 + scan_tiles(nblocks) + 1) * sizeof(uint64_t));
-        if (rc) return rc;
-        uint64_t *counts = (uint64_t *)ctx->misc.p;
-        uint64_t *total = counts + nblocks;
-        hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat, counts);
-        scan_u64(counts, nblocks, total, counts + nblocks + 2, st);
+    const bool known = !count_only && sel.valid && sel.R == R && sel.reso == reso && sel.notproc == notproc;
+    sel.valid = false;
+    int rc = pifu_ensure(ctx->sel_counts, (size_t)(nblocks + 2 + scan_tiles(nblocks) + 1) * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t *counts = (uint64_t *)ctx->sel_counts.p;
+    uint64_t *total = counts + nblocks;
+    hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat, counts);
+    scan_u64(counts, nblocks, total, counts + nblocks + 2, st);
+    int64_t n = sel.n;
+    if (!known) {
         PIFU_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PIFU_HIP(hipStreamSynchronize(st));
-        sel.n = (int64_t)(*(uint64_t *)ctx->pinned);
-        sel.R = R; sel.reso = reso; sel.notproc = notproc;
-        sel.valid = true;
+        n = (int64_t)(*(uint64_t *)ctx->pinned);
     }
-    const int64_t n = sel.n;
     *count_host = n;
-    if (count_only || n == 0) return PIFU_OK;
-    sel.valid = false;                      // the counts are consumed by this fill
+    if (count_only) {
+        sel.n = n; sel.R = R; sel.reso = reso; sel.notproc = notproc;
+        sel.valid = true;
+        return PIFU_OK;
+    }
+    if (n == 0) return PIFU_OK;
     PIFU_REQUIRE(index_out && cap >= n, PIFU_ERR_INVALID, "pifu_octree_select: index buffer holds %lld entries, %lld needed",
                  (long long)cap, (long long)n);
     hipLaunchKernelGGL(k_oct_scatter_index, dim3((unsigned)nblocks), dim3(256), 0, st, notproc, R, reso, nl, nlat,
-                       (const uint64_t *)ctx->misc.p, index_out);
+                       (const uint64_t *)counts, index_out, cap);
     PIFU_HIP(hipGetLastError());
     return PIFU_OK;
 }

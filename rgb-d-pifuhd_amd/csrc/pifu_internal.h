@@ -112,8 +112,9 @@ struct pifu_ctx {
     McState mc;
     // octree scratch
     DevBuf oct_arena;
-    // block counts of the last pifu_octree_select count call (kept in `misc`), so that the fill call of the same level
-    // needs neither a second counting pass nor a second host synchronisation
+    // pifu_octree_select: block counts / offsets of the running call (own buffer), and the total the last COUNT call brought
+    // to the host, so that the fill call of the same level needs no second host synchronisation
+    DevBuf sel_counts;
     struct SelState { bool valid = false; int R = 0, reso = 0; const uint8_t *notproc = nullptr; int64_t n = 0; } sel;
     // column tables of the lattice evaluation (column sharing)
     DevBuf col_arena;

@@ -172,39 +172,31 @@ def marching_cubes_slabs(ctx, volume, level, nslabs):
     return torch.cat(verts), torch.cat(faces)
 
 
-transform_fallbacks = 0      # times transform_verts() had to keep numpy's result (diagnostic)
-
-
 def transform_verts(ctx, verts_d, trans_mat):
     """`(trans_mat[:3, :3] @ verts.T + trans_mat[:3, 3:4]).T` in float64 (`mesh_util.py:87-89`) on the device
-    (`pifu_transform_verts`), returned as a host array.  The kernel evaluates the K = 3 products the way numpy's matmul does
-    (FMA chain in k order, translation added afterwards); a sample of the vertices is recomputed with numpy itself and, should
-    the BLAS of this machine round differently, numpy's result for all vertices is returned instead."""
+    (`pifu_transform_verts`).  Returns (host float64 [V, 3], the same array as a device tensor).  The kernel evaluates each
+    coordinate as the FMA chain `fma(m2, z, fma(m1, y, m0 * x))` followed by the addition of the translation - the order in
+    which an FMA-capable BLAS dgemm (what numpy's matmul calls for this shape) accumulates K = 3 - so the result is a fixed
+    function of its inputs on every machine; the tests compare it with numpy's matmul on the WHOLE array
+    (`tests/test_gpu_grid_mc.py`), nothing is sampled or recomputed here."""
     n = verts_d.shape[0]
     rows = np.ascontiguousarray(trans_mat[:3, :4], dtype=np.float64)
     out_d = torch.empty(n, 3, device=verts_d.device, dtype=torch.float64)
     _lib.call('pifu_transform_verts', ctx.h, _ptr(verts_d), n, rows.ctypes.data_as(C.c_void_p), _ptr(out_d),
               _stream_ptr(ctx.device))
-    out = out_d.cpu().numpy()
-    step = max(n // 2048, 1)
-    sample = verts_d[::step].cpu().numpy()
-    want = (np.matmul(trans_mat[:3, :3], sample.T) + trans_mat[:3, 3:4]).T
-    if not np.array_equal(out[::step], want):                  # pragma: no cover - depends on the host's BLAS
-        global transform_fallbacks
-        transform_fallbacks += 1
-        verts = verts_d.cpu().numpy()
-        return (np.matmul(trans_mat[:3, :3], verts.T) + trans_mat[:3, 3:4]).T
-    return out
+    return out_d.cpu().numpy(), out_d
 
 
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
-                   num_samples=10000, transform=None, return_sdf=False, sharded=False):
+                   num_samples=10000, transform=None, return_sdf=False, sharded=False, return_device_verts=False):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
     values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
     [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty.
     `sharded=True`: the grid evaluation is split over the ranks of the initialised process group
     (`pifuhd_amd.dist`); every rank gets the identical field; marching cubes runs redundantly on it, or - from
-    `dist.SLAB_MC_MIN_RESOLUTION` on - one axis-0 slab per rank (`dist.marching_cubes_sharded`), with the same result."""
+    `dist.SLAB_MC_MIN_RESOLUTION` on - one axis-0 slab per rank (`dist.marching_cubes_sharded`), with the same result.
+    `return_device_verts=True` appends the float64 vertices as a device tensor (the colour loop of `gen_mesh` continues
+    from it without a host round trip)."""
     ctx = _ctx_of(net)
     from . import dist as pdist
     if sharded and pdist.collective_active():
@@ -227,13 +219,15 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
         mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
         mat[0:3, 3] = -1.0
         trans_mat = np.matmul(calib_inv, mat)
-        verts = transform_verts(ctx, verts_d, trans_mat)                                  # mesh_util.py:87-89
+        verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)                       # mesh_util.py:87-89
         if np.linalg.det(trans_mat[:3, :3]) < 0.0:
             faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
         normals = np.zeros((0, 3), np.float32)
         values = np.zeros((0,), np.float32)
         if return_sdf:
             return verts, faces, normals, values, sdf
+        if return_device_verts:
+            return verts, faces, normals, values, verts_dev
         return verts, faces, normals, values
     except (ValueError, RuntimeError):
         print('error cannot marching cubes')                                             # mesh_util.py:94-96
@@ -341,7 +335,7 @@ class ObjFile:
     def __del__(self):                                   # an abandoned writer (exception between the two steps)
         if getattr(self, '_h', None):
             try:
-                _lib.call('pifu_obj_finish', self._h, None, None, 0)
+                _lib.call('pifu_obj_finish', self._h, None, None, -1)      # abandon: the file is not touched
             except Exception:
                 pass
             self._h = None

@@ -97,11 +97,14 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
 
     # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
     # like the reference (reconstruction.py:56)
-    verts, faces, _, _ = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh, use_octree=use_octree,
-                                        num_samples=5000, sharded=sharded)
+    verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
+                                                   use_octree=use_octree, num_samples=5000, sharded=sharded,
+                                                   return_device_verts=True)
     t3 = mark()
     obj = ObjFile(save_path, faces) if rank == 0 else None       # the face lines are formatted while the colours are computed
-    verts_tensor = torch.from_numpy(verts.T).unsqueeze(0).to(device=dev).float()
+    # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()` (reconstruction.py:57) without the host round trip:
+    # the float64 vertices are still on the device, and the float64 -> float32 cast rounds the same way there
+    verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
 
     spans = _normal_spans(len(verts))
     if any(r == l for (l, r) in spans):

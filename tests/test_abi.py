@@ -100,6 +100,16 @@ def test_obj_writer_host_only(lib, tmp_path):
     w = mesh_util.ObjFile(str(p), f[:0])
     w.finish(v[:0], c[:0])
     assert p.read_text() == ''
+    # a writer abandoned between the two steps (an exception in the colour loop) leaves the previous file as it was, and
+    # creates none where there was none - the reference writes only once everything has succeeded
+    p.write_text('previous result\n')
+    w = mesh_util.ObjFile(str(p), f)
+    del w
+    assert p.read_text() == 'previous result\n'
+    q = tmp_path / 'never.obj'
+    w = mesh_util.ObjFile(str(q), f)
+    del w
+    assert not q.exists()
 
 
 def test_checkpoint_io_roundtrip(tmp_path):

@@ -89,7 +89,6 @@ def _rccl_worker(port, outdir):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
@@ -142,8 +141,8 @@ def test_bench_dist_selftest_under_torchrun(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), 'bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--res', '64',
            '--genmesh-res', '64', '--batch-rows', '262144', '--dist-selftest', '--no-cpu-baseline', '--no-split-precision',
-           '--no-lean-pass', '--no-canonical', '--no-smooth-genmesh']
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+           '--no-lean-pass', '--no-canonical', '--no-smooth-genmesh', '--config5-res', '64']
+    env = dict(os.environ)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
@@ -218,18 +217,26 @@ def test_slab_marching_cubes_world3_matches_the_replicated_run(tmp_path):
 
 
 @pytest.mark.timeout(900)
-def test_bench_two_ranks_on_one_gpu_under_torchrun():
+@pytest.mark.parametrize('launcher', ['torchrun', 'plain'])
+def test_bench_two_ranks_on_one_gpu(launcher):
     """The N > 1 form of bench.py, launched the way the driver launches it (`python -m torch.distributed.run --nproc-per-node
-    2 ... bench.py --gpus 2`), with both ranks sharing this box's one GPU over gloo (PIFU_BENCH_ONE_GPU: RCCL refuses two
+    2 ... bench.py --gpus 2`) and PLAINLY (`python bench.py --gpus 2`: bench.py starts its ranks itself, as a fresh child,
+    before it touches the GPU), with both ranks sharing this box's one GPU over gloo (PIFU_BENCH_ONE_GPU: RCCL refuses two
     ranks on one device): slab-sharded lattice with the all-gather inside the timed region, max-over-ranks timing, the
-    sharded gen_mesh of one subject and the independent subjects, ONE JSON line from rank 0.  A rehearsal, not a number."""
+    sharded gen_mesh of one subject, the independent subjects and the config-5 leg, ONE JSON line from rank 0.  A rehearsal,
+    not a number."""
     import json
     import subprocess
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--res', '64',
-           '--genmesh-res', '64', '--batch-rows', '262144', '--no-split-precision', '--no-lean-pass', '--no-canonical']
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PIFU_BENCH_ONE_GPU='1')
+    tail = ['--gpus', '2', '--steps', '1', '--warmup', '1', '--res', '64', '--genmesh-res', '64', '--config5-res', '128',
+            '--batch-rows', '262144', '--no-split-precision', '--no-lean-pass', '--no-canonical']
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), 'bench.py'] + tail
+    else:
+        cmd = [sys.executable, 'bench.py'] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['PIFU_BENCH_ONE_GPU'] = '1'
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -240,3 +247,124 @@ def test_bench_two_ranks_on_one_gpu_under_torchrun():
     gm = line['gen_mesh']
     assert 'error' not in gm['one_subject_sharded'] and gm['one_subject_sharded']['n_verts'] > 0
     assert 'error' not in gm['independent_subjects'] and gm['independent_subjects']['subjects'] == 2
+    assert 'error' not in gm['config5_1024'], gm['config5_1024']
+    assert gm['config5_1024']['mesh_identical_on_all_ranks'] and gm['config5_1024']['n_verts'] > 0
+
+
+@pytest.mark.timeout(700)
+def test_bench_a_failed_rank_ends_the_job():
+    """A rank that fails must end the job with a non-zero code instead of leaving its siblings in a collective: rank 1 raises
+    before the first all-gather (PIFU_BENCH_FAIL_RANK, a test hook), rank 0 is already waiting in it; the launcher ends rank 0
+    and the plain `python bench.py --gpus 2` call hands the failure back."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(PIFU_BENCH_ONE_GPU='1', PIFU_BENCH_FAIL_RANK='1')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--res', '64', '--no-genmesh', '--no-cpu-baseline',
+                        '--features', 'synthetic'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'test hook' in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] as far as one GPU reaches: ONE subject on a 1024^3 grid, two ranks (gloo, both on this box's GPU),
+# octree levels sharded by chunk ranges, marching cubes over one axis-0 slab per rank with dist.SLAB_MC_MIN_RESOLUTION at
+# its real value (1024), colour loop sharded by calc_normal calls.
+# ---------------------------------------------------------------------------------------------------------------------
+def _build_1024():
+    """The tiny golden nets with the MLP weights at a scale that keeps the 1024^3 surface at a few million vertices."""
+    from pifuhd_amd import nets, synth
+    from helpers import golden_nets
+    sd, oc, of = golden_nets(mlp_std=0.03)
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = _data()
+    netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
+    return netMR, data
+
+
+def _digest(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _worker_1024(rank, ws, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import dist as pdist, reconstruction
+    assert pdist.SLAB_MC_MIN_RESOLUTION == 1024
+    netMR, data = _build_1024()
+    timings = {}
+    verts, faces, color = reconstruction.gen_mesh(1024, netMR, 'cuda', data, os.path.join(outdir, f'm1024_r{rank}.obj'),
+                                                  sharded=True, timings=timings)
+    with open(os.path.join(outdir, f'sha1024_r{rank}.txt'), 'w') as f:
+        f.write(_digest(verts, faces, color))
+    if rank == 0:
+        np.savez(os.path.join(outdir, 'mesh1024_r0.npz'), verts=verts, faces=faces, color=color)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1100)
+def test_gen_mesh_1024_sharded_world2_with_slab_marching_cubes(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mpctx = mp.get_context('spawn')
+    procs = [mpctx.Process(target=_worker_1024, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=1000)
+        assert p.exitcode == 0
+    shas = [open(tmp_path / f'sha1024_r{r}.txt').read() for r in range(2)]
+    assert shas[0] == shas[1]                                             # every rank holds the same mesh
+    assert os.path.exists(tmp_path / 'm1024_r0.obj') and not os.path.exists(tmp_path / 'm1024_r1.obj')
+
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import _lib, reconstruction
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netMR, data = _build_1024()
+    verts, faces, color = reconstruction.gen_mesh(1024, netMR, 'cuda', data, str(tmp_path / 'single1024.obj'))
+    assert _digest(verts, faces, color) == shas[0]                        # ... and it is the single-process mesh, bit for bit
+    got = np.load(tmp_path / 'mesh1024_r0.npz')
+    assert np.array_equal(got['faces'], faces) and np.array_equal(got['verts'], verts) and np.array_equal(got['color'], color)
+    # rank 0's file is the single-process file
+    import filecmp
+    assert filecmp.cmp(tmp_path / 'm1024_r0.obj', tmp_path / 'single1024.obj', shallow=False)
+
+    # size-independent properties of the mesh.  A Lewiner surface is a closed 2-manifold wherever it does not leave the
+    # volume: every edge is used by exactly two triangles, in opposite directions, except edges lying in a face of the box.
+    V, F = len(verts), len(faces)
+    assert V > 100000 and F > 200000
+    f64 = faces.astype(np.int64)
+    a = np.concatenate([f64[:, 0], f64[:, 1], f64[:, 2]])
+    b = np.concatenate([f64[:, 1], f64[:, 2], f64[:, 0]])
+    directed = a * V + b
+    assert len(np.unique(directed)) == len(directed)                      # no directed edge twice: consistent orientation
+    und, cnt = np.unique(np.minimum(a, b) * V + np.maximum(a, b), return_counts=True)
+    odd = und[cnt != 2]
+    grid = (verts * np.array([1.0, -1.0, 1.0]) + 1.0) * (1024 / 2.0)      # calib = diag(1, -1, 1): back to node coordinates
+    on_box = ((np.abs(grid) < 1e-6) | (np.abs(grid - 1023.0) < 1e-6)).any(1)
+    assert on_box[odd // V].all() and on_box[odd % V].all()
+    assert (cnt <= 2).all()
+    E = len(und)
+    chi = V - E + F
+    # components from the device union-find (the meshcleaning kernel): chi = 2 (components - genus) for the closed ones
+    ctx = netMR._ctx
+    fd = torch.from_numpy(np.ascontiguousarray(faces, dtype=np.int32)).cuda()
+    label = torch.empty(F, device='cuda', dtype=torch.int32)
+    open_edge = torch.empty(F, device='cuda', dtype=torch.uint8)
+    _lib.call('pifu_face_components', ctx.h, _ptr(fd), F, _ptr(label), _ptr(open_edge), _stream_ptr(ctx.device))
+    ncomp = len(torch.unique(label))
+    if len(odd) == 0:
+        assert chi % 2 == 0 and chi <= 2 * ncomp
+    print(f'1024^3 sharded gen_mesh: V={V} F={F} E={E} chi={chi} components={ncomp} open_edges={len(odd)}')
