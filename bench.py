@@ -131,7 +131,6 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     """gen_mesh wall time on N GPUs: (a) ONE subject, grid evaluation + colour loop sharded (max over ranks);
     (b) N subjects, one per GPU, no communication (time for all N to finish).  Every rank always takes part in every
     collective, also after a local failure (reported as an error string), so a bad subject cannot hang the job."""
-    import tempfile
     import torch
     from pifuhd_amd import reconstruction as recon
     res = {'resolution': args.genmesh_res, 'use_octree': True, 'n_gpus': world}
@@ -621,7 +620,6 @@ def main():
 
     # ---- second half of the metric: end-to-end gen_mesh wall time (single GPU) ---------------------------
     if world == 1 and not args.no_genmesh and args.features == 'filter':
-        import tempfile
         from pifuhd_amd import mesh_util, reconstruction as recon
         with tempfile.TemporaryDirectory() as td:
             timings = {}

@@ -149,3 +149,41 @@ def test_reloading_weights_into_a_live_net_refreshes_every_derived_buffer():
         netMR.load_state_dict({**sd_b, 'netG.mlp.filters.9.weight': torch.zeros(1)})
     with pytest.raises(RuntimeError, match='Missing key'):
         netMR.load_state_dict({k: v for k, v in sd_b.items() if k != 'mlp.filters.0.bias'})
+
+
+def test_full_size_encoders_to_occupancy_end_to_end(golden_dir):
+    """The path END TO END at full size against the reference's own run of it (`tests/golden/make_golden_r3.py e2e_full`):
+    `filter_global` on the 512^2 image, `filter_local` on the 1024^2 image, then `query` on 4 096 seeded points - the
+    occupancy the real encoders' feature maps lead to, not features compared on their own - within the north star's 1e-4;
+    `calc_normal` on the first 1 024 points.  (`PIFuMRNet.py:71-186`, `:188-243`.)"""
+    from helpers import seeded_points
+    from pifuhd_amd import config, nets, synth
+    gold = np.load(os.path.join(golden_dir, 'e2e_full.npz'))
+    seed, n, lim = int(gold['seed_points_lim'][0]), int(gold['seed_points_lim'][1]), float(gold['seed_points_lim'][2])
+    oc = config.coarse_opt(); of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    last = sorted(k for k in sd if k.startswith('mlp.filters.') and k.endswith('.bias'))[-1]
+    sd[last] = sd[last] + float(gold['fine_last_bias_key_shift'][0])
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = synth.synthetic_inputs(1024, 3, seed=0)
+    netMR.filter_global(data['img_512'])
+    netMR.filter_local(data['img'][:, None])
+    pts = seeded_points(seed, n, lim=lim)
+    calib = data['calib']
+    netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)
+    preds = netMR.get_preds().cpu().numpy().reshape(-1)
+    want = gold['preds']
+    assert 0.2 < (want > 0.5).mean() < 0.8                               # the sample straddles the surface
+    err = np.abs(preds - want).max()
+    print('end-to-end occupancy: max abs diff %.2e (coarse %.2e)' %
+          (err, np.abs(netG.get_preds().cpu().numpy().reshape(-1) - gold['preds_low']).max()))
+    assert err < 1e-4
+    assert np.abs(netG.get_preds().cpu().numpy().reshape(-1) - gold['preds_low']).max() < 1e-4
+    assert _rel(netG.phi[0, ::8, ::16].cpu().numpy(), gold['phi_sub']) < 5e-4
+    m = int(gold['nmls'].shape[1])
+    netMR.calc_normal(pts[:, None, :, :m], calib[:, None], calib)
+    got_n, want_n = netMR.nmls.cpu().numpy()[0], gold['nmls']
+    # unit normals from finite differences of occupancies that agree to ~1e-6: compare directions where the gradient
+    # is not vanishing (the reference divides by |g| + 1e-8)
+    cos = (got_n * want_n).sum(0)
+    assert np.median(cos) > 0.999 and (cos > 0.9).mean() > 0.97

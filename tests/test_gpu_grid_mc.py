@@ -565,3 +565,73 @@ def test_full_size_marching_cubes_properties(ctx):
     assert float((r - 0.45).abs().max()) < 1.5 * 1.5 * (2.0 / R)        # within a cell of the level set (largest axis scale 1.5)
     v2, f2 = mesh_util.marching_cubes_device(ctx, vol, 0.5)
     assert torch.equal(f, f2) and torch.equal(v.view(torch.int32), v2.view(torch.int32))
+
+
+@pytest.mark.parametrize('init', [64, 16])
+def test_multi_level_network_octree_composition_vs_oracle(init):
+    """The COMPOSITION `pifu_eval_grid` runs for gen_mesh - several octree levels, each level's points chosen from the SDF
+    the previous levels left, evaluated by the network (column sharing, depth walk, 5000-point GroupNorm chunks cut from
+    the level's own index list), committed and block-filled - against the same composition on the CPU oracle
+    (`mesh_util.py:124-187` + `PIFuMRNet.query`): R = 128 with init_resolution 64 (two levels) and 16 (four levels).  The
+    levels must select the same number of points, the float64 SDF must agree within the north star's 1e-4, the fused
+    device loop must equal the level-by-level ABI calls bit for bit, and marching cubes on the device SDF must be the
+    serial oracle's on that SDF, vertices and faces."""
+    import ctypes as C
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, mesh_util, nets
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    R, chunk = 128, 5000
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(9)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    calib_t = calib_tensor()
+    calib, cinv = mesh_util.calib_pair(calib_t)
+
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+
+    def field(pts):
+        with torch.no_grad():
+            return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib_t)[0, 0].numpy()
+    stats = []
+    want = O.eval_grid_octree(R, cinv, field, chunk, init_resolution=init, stats=stats)
+    assert len(stats) == {64: 2, 16: 4}[init] and all(n > 0 for _, n in stats)
+
+    # the fused device loop
+    sdf, n_eval = mesh_util.eval_grid_device(netMR, calib_t, R, chunk, True, init_resolution=init)
+    assert n_eval == sum(n for _, n in stats)
+    got = sdf.cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+    # the same composition level by level through the public octree entry points: per-level counts, identical SDF
+    ctx = netMR._ctx
+    st = _stream_ptr(ctx.device)
+    res_a = (C.c_int32 * 3)(R, R, R)
+    sdf2 = torch.empty(R, R, R, device='cuda', dtype=torch.float64)
+    notproc = torch.empty(R, R, R, device='cuda', dtype=torch.uint8)
+    _lib.call('pifu_octree_begin', ctx.h, R, _ptr(sdf2), _ptr(notproc), st)
+    reso, levels = R // init, []
+    while reso > 0:
+        cnt = C.c_int64(0)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st)
+        n = cnt.value
+        levels.append((reso, n))
+        idx = torch.empty(n, device='cuda', dtype=torch.int64)
+        vals = torch.empty(n, device='cuda', dtype=torch.float32)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
+        _lib.call('pifu_eval_lattice', ctx.h, res_a, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  _ptr(idx), 0, n, chunk, 0, _ptr(vals), st)
+        _lib.call('pifu_octree_commit', ctx.h, R, reso, 0.05, _ptr(idx), _ptr(vals), n, _ptr(sdf2), _ptr(notproc), st)
+        if reso <= 1:
+            break
+        reso //= 2
+    assert levels == stats
+    assert torch.equal(sdf2, sdf)
+
+    # marching cubes on the device SDF: the serial oracle on the same volume, bit for bit
+    gv, gf = mesh_util.marching_cubes_device(ctx, sdf, 0.5)
+    ov, of_ = O.marching_cubes_lewiner(got, 0.5)
+    assert len(ov) > 1000
+    assert np.array_equal(gf.cpu().numpy(), of_) and np.array_equal(gv.cpu().numpy().view(np.uint32), ov.view(np.uint32))
