@@ -201,8 +201,8 @@ int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64
 /* ---- vertex back-transform of reconstruction() (mesh_util.py:87-89): verts = (trans_mat[:3,:3] @ verts.T + trans_mat[:3,3:4]).T
  * in float64 on the float32 marching-cubes vertices.  verts: device fp32 [n][3]; mat: HOST double [12] = rows of the 3x4
  * trans_mat; out: device double [n][3].  Per component: the three products accumulated by FMA in k order starting from the
- * first product, the translation added last - what numpy's matmul (a BLAS dgemm) evaluates for this K = 3 product (the host
- * wrapper checks a sample of the vertices against numpy on the machine it runs on and keeps numpy's result if they differ). */
+ * first product, the translation added last - the order an FMA-capable BLAS dgemm (what numpy's matmul calls) accumulates
+ * K = 3 in; a fixed function of its inputs, compared with numpy on whole arrays by the tests. */
 int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream);
 
 /* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
@@ -223,8 +223,10 @@ int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const
  * trimesh's `mesh.split()` (reconstruction.py:331-332; trimesh is a third-party dependency absent from this image, its
  * split semantics are restated: faces are adjacent when they share an edge that exactly two faces use).  faces: device
  * int32 [nfaces][3]; label (device int32 [nfaces]) receives the SMALLEST face index of each face's component; open_edge
- * (device uint8 [nfaces]) is 1 for faces with an edge that is not shared by exactly two faces (a component is watertight
- * iff none of its faces is flagged).
+ * (device uint8 [nfaces]): bit 0 = the face has an edge no other face uses (its component cannot be watertight), bit 1 =
+ * it has an edge that three or more faces use (no adjacency through it; trimesh judges watertightness per component, so
+ * such an edge still counts as closed for a component holding exactly two of its faces - the caller, who has the labels,
+ * settles these few faces).  A component none of whose faces is flagged is watertight.
  * pifu_esti_color: `esti_color` (reconstruction.py:180-229), exact: xyz = projected vertices, device fp32 [3][n]; color:
  * device uint16 [n][4] (RGBA), updated in place - every vertex with z < 0 receives the mean (uint16 sums, float64 division,
  * truncation) of the colours of its <= 10 nearest silhouette vertices (0 <= z < 0.001) on the left (x_s < x: ordered by

@@ -586,6 +586,55 @@ def face_components(faces: np.ndarray):
     return np.array([find(f) for f in range(len(F))], dtype=np.int32), open_face
 
 
+def merge_vertices(verts: np.ndarray, colours: np.ndarray, faces: np.ndarray):
+    """What `trimesh.load(obj_path)` (default `process=True`, `reconstruction.py:332`) does to the vertex list before
+    `split()` sees it - RESTATED from trimesh's published `merge_vertices` (trimesh is not installed here: parity unpinned):
+    referenced vertices whose positions agree (rounded to 8 decimals; the OBJ holds 4) become one vertex, the first
+    occurrence is kept with its colour, kept vertices stay in their original order, unreferenced vertices are dropped and
+    the faces are re-indexed.  Faces are NOT filtered: triangles that become degenerate stay (`validate=False`).
+    Returns (verts, colours, faces)."""
+    F = np.asarray(faces, dtype=np.int64)
+    key_of, order, remap = {}, [], np.full(len(verts), -1, dtype=np.int64)
+    referenced = np.zeros(len(verts), dtype=bool)
+    referenced[F.reshape(-1)] = True
+    for i in np.flatnonzero(referenced):
+        k = tuple(np.round(np.asarray(verts[i], dtype=np.float64) * 1e8).astype(np.int64))
+        if k not in key_of:
+            key_of[k] = len(order)
+            order.append(i)
+        remap[i] = key_of[k]
+    order = np.asarray(order, dtype=np.int64)
+    return verts[order], colours[order], remap[F].astype(np.int32)
+
+
+def widest_watertight_component(verts: np.ndarray, faces: np.ndarray):
+    """`mesh.split()` + the selection loop of `meshcleaning` (`reconstruction.py:333-342`), restated from trimesh's published
+    behaviour: faces are adjacent iff they share an edge that exactly two faces of the mesh use; a component counts only
+    if it is watertight ON ITS OWN (every edge of its faces is used exactly twice among ITS faces - an edge that three
+    faces of the whole mesh share can still pair up inside one component); components are visited in the order of their
+    smallest face index and the first one with the largest extent along axis 0 wins.  Returns the ascending face indices
+    of that component; raises IndexError when no component qualifies (`cc[0]` on an empty list)."""
+    F = np.asarray(faces, dtype=np.int64)
+    label, _ = face_components(F)
+    best, best_ext = None, None
+    for r in np.unique(label):
+        idx = np.flatnonzero(label == r)
+        count = {}
+        for f in idx:
+            a, b, c = F[f]
+            for u, v in ((a, b), (b, c), (c, a)):
+                k = (min(u, v), max(u, v))
+                count[k] = count.get(k, 0) + 1
+        if any(n != 2 for n in count.values()):
+            continue
+        ext = np.ptp(verts[:, 0][F[idx]])
+        if best is None or best_ext < ext:
+            best, best_ext = idx, ext
+    if best is None:
+        raise IndexError('list index out of range')
+    return best
+
+
 def analytic_field(points: np.ndarray) -> np.ndarray:
     """Network-independent test field of SURVEY 8d: sigmoid((0.35 - |(0.8x,0.45y,1.6z)|) / 0.01)."""
     r = np.sqrt((0.8 * points[0]) ** 2 + (0.45 * points[1]) ** 2 + (1.6 * points[2]) ** 2)

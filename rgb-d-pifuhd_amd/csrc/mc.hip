@@ -23,15 +23,11 @@ namespace {
 
 constexpr double MC_EPS = 2.220446049250313e-16;
 
-__device__ __constant__ const signed char EDGE_A[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};
-__device__ __constant__ const signed char EDGE_B[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
 // corner -> (dx,dy,dz)
 __device__ __constant__ const signed char COFF[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
-// edge -> axis (0 = x, 1 = y, 2 = z), base-point offset (dx,dy,dz) of its lower endpoint, and the mask of
-// cell coordinates (bit0 x, bit1 y, bit2 z) that must be 0 for this cell to be the first one touching it
-__device__ __constant__ const signed char EDGE_AXIS[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
-__device__ __constant__ const signed char EDGE_BASE[12][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 0}, {0, 0, 1}, {1, 0, 1},
-                                                             {0, 1, 1}, {0, 0, 1}, {0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}};
+// edge e joins corners {0,1,2,3,4,5,6,7,0,1,2,3}[e] and {1,2,3,0,5,6,7,4,4,5,6,7}[e]; its axis (0 = x, 1 = y, 2 = z) and the
+// offset of its lower endpoint are the immediates EDGE_AXIS_BITS / EDGE_BASE_BITS further down.  EDGE_NEEDZERO: the mask of
+// cell coordinates (bit0 x, bit1 y, bit2 z) that must be 0 for this cell to be the first one touching the edge
 __device__ __constant__ const signed char EDGE_NEEDZERO[12] = {2 | 4, 4, 4, 1 | 4, 2, 0, 0, 1, 1 | 2, 2, 0, 1};
 // interior-test table e:(p,q,(b0,b1),(c0,c1),(d0,d1))
 __device__ __constant__ const signed char TI[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7},
@@ -181,7 +177,7 @@ struct Vol {
     int c0, c1, c2;            // cells per axis
     int64_t ncells;
     double level;
-    // 8 x 8 x 8-cell bricks whose 9 x 9 x 9 nodes are not all on one side of the level (k_mc_bricks); null = classify every cell
+    // 8 x 8 x 8-cell bricks whose 9 x 9 x 9 nodes are not all on one side of the level (k_mc_nodebricks + k_mc_brick_combine); null = classify every cell
     const uint8_t *brick;
     int b0, b1, b2;
     // 1 for every group of 256 consecutive cells of the serial scan that touches such a brick (k_mc_groups); the three
@@ -202,11 +198,12 @@ struct CellInfo {
     const signed char *row;
     int nt;
     int nown;                  // vertices this cell creates
+    uint64_t own;              // their edge ids (12 = the centre vertex), 4 bits each, in the order the cell numbers them
     int x, y, z;
     double c[8];
 };
 
-// classify one cell; fills c[], row, nt and counts owned vertices.  Returns false for an empty cell.
+// classify one cell; fills c[], row, nt and the owned vertices.  Returns false for an empty cell.
 __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
 {
     ci.x = (int)(cell % v.c2);
@@ -214,6 +211,7 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
     ci.z = (int)(cell / ((int64_t)v.c2 * v.c1));
     ci.nt = 0;
     ci.nown = 0;
+    ci.own = 0;
     ci.row = nullptr;
     // a cell of a brick whose nodes all lie on one side of the level has index 0 or 255: nothing to load
     if (v.brick && !v.brick[((size_t)(ci.z >> 3) * v.b1 + (ci.y >> 3)) * v.b2 + (ci.x >> 3)]) return false;
@@ -223,9 +221,6 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
         ci.c[i] = vol_at(v, ci.z + COFF[i][2], ci.y + COFF[i][1], ci.x + COFF[i][0]) - v.level;
         if (ci.c[i] > 0) index |= 1 << i;
     }
-    ci.nt = 0;
-    ci.nown = 0;
-    ci.row = nullptr;
     if (index == 0 || index == 255) return false;
     ci.nt = choose_tiling(ci.c, index, &ci.row);
     const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
@@ -234,20 +229,58 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
         const int e = ci.row[k];
         if (seen & (1u << e)) continue;
         seen |= 1u << e;
-        if (e == 12 || (EDGE_NEEDZERO[e] & ~zero_mask) == 0) ++ci.nown;
+        if (e == 12 || (EDGE_NEEDZERO[e] & ~zero_mask) == 0) {
+            ci.own |= (uint64_t)e << (4 * ci.nown);
+            ++ci.nown;
+        }
     }
     return true;
 }
 
-__global__ void k_mc_minmax(const Vol v, float *out /* [2*gridDim] */)
+// ---- pass 0: value range + which 8 x 8 x 8-cell bricks can hold a surface cell, from ONE coalesced pass over the nodes -------
+// A cell brick b needs the nodes [8 b, 8 b + 8] of every axis: node brick b (8 x 8 x 8 nodes) plus the first node planes /
+// lines / corner of its upper neighbours.  k_mc_nodebricks reads every node once - a block per (z brick, y brick) pencil,
+// consecutive threads on consecutive x - and leaves per node brick, for each of the 8 sub-regions "nodes whose local
+// coordinates in the axes of set r are 0", whether a positive and whether a non-positive value of (v - level) occurs,
+// evaluated exactly as classify() does; k_mc_brick_combine ORs the 8 pieces a cell brick consists of.
+// region sets: bit 0 = x, bit 1 = y, bit 2 = z.  A node whose zero coordinates are Z belongs to every region r subset of Z.
+__device__ __forceinline__ unsigned regions_of(unsigned Z)
+{
+    // bit r set iff (r & ~Z) == 0, for Z = 0..7: 0x01, 0x03, 0x05, 0x0f, 0x11, 0x33, 0x55, 0xff
+    return (unsigned)((0xff553311'0f050301ull >> (8 * Z)) & 0xffu);
+}
+
+__global__ __launch_bounds__(256) void k_mc_nodebricks(const Vol v, int nb1, int nb2, uint16_t *nbflags, float *mm /* [2*gridDim] */)
 {
     __shared__ float smin[4], smax[4];
-    const int64_t n = (int64_t)v.n0 * v.n1 * v.n2;
+    const int by = blockIdx.x % nb1, bz = blockIdx.x / nb1;
     float lo = INFINITY, hi = -INFINITY;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float f = v.dtype == 0 ? ((const float *)v.p)[i] : (float)((const double *)v.p)[i];
-        lo = fminf(lo, f);
-        hi = fmaxf(hi, f);
+    for (int x0 = 0; x0 < nb2 * 8; x0 += 256) {
+        const int x = x0 + threadIdx.x;
+        unsigned pos = 0, neg = 0;
+        if (x < v.n2) {
+            const unsigned zx = (x & 7) == 0 ? 1u : 0u;
+            for (int dz = 0; dz < 8; ++dz) {
+                const int z = bz * 8 + dz;
+                if (z >= v.n0) break;                                        // block-uniform
+#pragma unroll
+                for (int dy = 0; dy < 8; ++dy) {
+                    const int y = by * 8 + dy;
+                    if (y >= v.n1) break;                                    // block-uniform
+                    const size_t i = ((size_t)z * v.n1 + y) * v.n2 + x;
+                    const float f = v.dtype == 0 ? ((const float *)v.p)[i] : (float)((const double *)v.p)[i];
+                    lo = fminf(lo, f);
+                    hi = fmaxf(hi, f);
+                    const unsigned reg = regions_of(zx | (dy == 0 ? 2u : 0u) | (dz == 0 ? 4u : 0u));
+                    if (((double)f - v.level) > 0) pos |= reg; else neg |= reg;
+                }
+            }
+        }
+        unsigned both = pos | (neg << 8);
+        both |= __shfl_xor(both, 1);
+        both |= __shfl_xor(both, 2);
+        both |= __shfl_xor(both, 4);
+        if ((threadIdx.x & 7) == 0 && (x >> 3) < nb2) nbflags[((size_t)bz * nb1 + by) * nb2 + (x >> 3)] = (uint16_t)both;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -257,8 +290,8 @@ __global__ void k_mc_minmax(const Vol v, float *out /* [2*gridDim] */)
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2 * blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        out[2 * blockIdx.x + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        mm[2 * blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        mm[2 * blockIdx.x + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
     }
 }
 
@@ -274,29 +307,25 @@ __global__ void k_mc_minmax_final(const float *part, int n, float *out)
     if (threadIdx.x == 0) { out[0] = lo; out[1] = hi; }
 }
 
-// pass 0: one wave per 8 x 8 x 8-cell brick: does the sign of (value - level) - evaluated exactly as classify() does -
-// change anywhere among its 9 x 9 x 9 nodes?  ~96 % of the cells of a body at 512^3 sit in bricks where it does not; the
-// three classification passes then skip them without touching the volume.
-__global__ void k_mc_bricks(const Vol v, uint8_t *brick)
+__global__ void k_mc_brick_combine(const Vol v, int nb0, int nb1, int nb2, const uint16_t *nbflags, uint8_t *brick)
 {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nb = (int64_t)v.b0 * v.b1 * v.b2;
     if (b >= nb) return;
     const int bx = (int)(b % v.b2), by = (int)((b / v.b2) % v.b1), bz = (int)(b / ((int64_t)v.b2 * v.b1));
-    bool pos = false, neg = false;
-    for (int i = lane; i < 729; i += 64) {
-        const int dz = i / 81, dy = (i / 9) % 9, dx = i % 9;
-        const int z = min(bz * 8 + dz, v.n0 - 1), y = min(by * 8 + dy, v.n1 - 1), x = min(bx * 8 + dx, v.n2 - 1);
-        const bool p = (vol_at(v, z, y, x) - v.level) > 0;
-        pos |= p;
-        neg |= !p;
+    unsigned pos = 0, neg = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                                        // the neighbour shifted along the axes of set s ...
+        const int qx = bx + (s & 1), qy = by + ((s >> 1) & 1), qz = bz + ((s >> 2) & 1);
+        if (qx >= nb2 || qy >= nb1 || qz >= nb0) continue;               // ... if the volume has nodes there
+        const unsigned f = nbflags[((size_t)qz * nb1 + qy) * nb2 + qx];
+        pos |= (f >> s) & 1u;                                            // ... contributes its region "zero along those axes"
+        neg |= (f >> (8 + s)) & 1u;
     }
-    const bool any_pos = __builtin_amdgcn_ballot_w64(pos) != 0ull, any_neg = __builtin_amdgcn_ballot_w64(neg) != 0ull;
-    if (lane == 0) brick[b] = (any_pos && any_neg) ? 1 : 0;
+    brick[b] = (pos && neg) ? 1 : 0;
 }
 
-constexpr int MC_GPB = 16;      // groups of 256 cells per block of the classification passes
+constexpr int MC_GPB = 16;      // groups of 256 cells per block of the counting pass
 
 // which groups of 256 consecutive cells can hold a surface cell at all: one thread per group walks its cells brick by brick
 __global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)
@@ -315,28 +344,64 @@ __global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)
     gflag[g] = any;
 }
 
-// pass 1: group g covers cells [256 g, 256 g + 256) of the serial scan; per-group (vertices, triangles) created
-__global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_verts, uint64_t *blk_tris)
+// The surface cells, compacted.  One record per cell with at least one triangle, written by the counting pass - the only
+// pass that classifies - and read by the two emit passes with one lane per RECORD (full waves, no second classification).
+// Records of one group are contiguous; groups take their place in the list by an atomic counter, so the list order varies
+// from run to run, the meshes do not: every record carries what fixes its output positions (its cell, hence its group, and
+// its exclusive vertex / triangle prefixes inside the group).
+struct SurfList {
+    int64_t *cell;             // serial cell number
+    const signed char **row;   // triangle row (edge ids, 3 per triangle) in the constant tables
+    uint64_t *own;             // CellInfo::own
+    uint32_t *meta;            // vertices before it in the group (12 bits) | triangles before it (12) | nown (4) | nt (4)
+    int64_t cap;
+};
+
+// pass 1: group g covers cells [256 g, 256 g + 256) of the serial scan; per group (vertices << 32 | triangles) created,
+// and the records of its surface cells
+__global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const SurfList L, unsigned long long *nsurf)
 {
     __shared__ uint32_t sh[4];
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long base_sh;
     for (int gi = 0; gi < MC_GPB; ++gi) {
         const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
         if (group >= ngroups) break;
         if (!v.gflag[group]) {                                   // block-uniform
-            if (threadIdx.x == 0) { blk_verts[group] = 0; blk_tris[group] = 0; }
+            if (threadIdx.x == 0) blk_vt[group] = 0;
             continue;
         }
         const int64_t cell = group * 256 + threadIdx.x;
-        uint32_t packed = 0;
-        if (cell < v.ncells) {
-            CellInfo ci;
-            if (classify(v, cell, ci)) packed = (uint32_t)ci.nown | ((uint32_t)ci.nt << 16);
-        }
+        CellInfo ci;
+        bool active = false;
+        if (cell < v.ncells) active = classify(v, cell, ci);
+        const uint32_t packed = active ? ((uint32_t)ci.nown | ((uint32_t)ci.nt << 16)) : 0u;
         uint32_t tot;
-        block_exclusive_scan_256(packed, sh, &tot);
+        const uint32_t pre = block_exclusive_scan_256(packed, sh, &tot);
+        // position among the group's surface cells
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(active);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t spre = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)), stot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) spre += wcnt[w];
+            stot += wcnt[w];
+        }
         if (threadIdx.x == 0) {
-            blk_verts[group] = tot & 0xffffu;
-            blk_tris[group] = tot >> 16;
+            blk_vt[group] = ((uint64_t)(tot & 0xffffu) << 32) | (uint64_t)(tot >> 16);
+            base_sh = stot ? atomicAdd(nsurf, (unsigned long long)stot) : 0ull;
+        }
+        __syncthreads();
+        if (active) {
+            const int64_t slot = (int64_t)base_sh + spre;
+            if (slot < L.cap) {                                  // past the capacity: counted only, the host grows the list and reruns
+                L.cell[slot] = cell;
+                L.row[slot] = ci.row;
+                L.own[slot] = ci.own;
+                L.meta[slot] = (pre & 0xfffu) | (((pre >> 16) & 0xfffu) << 12) | ((uint32_t)ci.nown << 24) | ((uint32_t)ci.nt << 28);
+            }
         }
     }
 }
@@ -346,51 +411,49 @@ __device__ __forceinline__ size_t edge_slot(const Vol &v, int axis, int z, int y
     return (size_t)axis * v.n0 * v.n1 * v.n2 + ((size_t)z * v.n1 + y) * v.n2 + x;
 }
 
-// pass 2: vertex positions + per-grid-edge vertex index volume
-__global__ void k_mc_verts(const Vol v, int64_t ngroups, const uint64_t *blk_verts, int64_t vert_base, float *verts,
-                           int32_t *edge_index)
+// edge -> axis (2 bits each) and base-point offset (dx | dy << 1 | dz << 2, 3 bits each) as immediates: EDGE_AXIS / EDGE_BASE
+constexpr uint32_t EDGE_AXIS_BITS = 0u | (1u << 2) | (0u << 4) | (1u << 6) | (0u << 8) | (1u << 10) | (0u << 12) | (1u << 14) |
+                                    (2u << 16) | (2u << 18) | (2u << 20) | (2u << 22);
+constexpr uint64_t EDGE_BASE_BITS = 0ull | (1ull << 3) | (2ull << 6) | (0ull << 9) | (4ull << 12) | (5ull << 15) | (6ull << 18) |
+                                    (4ull << 21) | (0ull << 24) | (1ull << 27) | (3ull << 30) | (2ull << 33);
+
+// pass 2: one lane per surface cell: vertex positions + per-grid-edge vertex index volume
+__global__ __launch_bounds__(256) void k_mc_verts(const Vol v, const SurfList L, int64_t nsurf, const uint64_t *blk_vt,
+                                                  int64_t vert_base, float *verts, int32_t *edge_index)
 {
-    __shared__ uint32_t sh[4];
-  for (int gi = 0; gi < MC_GPB; ++gi) {
-    const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
-    if (group >= ngroups) break;
-    if (!v.gflag[group]) continue;                               // block-uniform
-    const int64_t cell = group * 256 + threadIdx.x;
-    CellInfo ci;
-    bool active = false;
-    if (cell < v.ncells) active = classify(v, cell, ci);
-    uint32_t tot;
-    const uint32_t pre = block_exclusive_scan_256(active ? (uint32_t)ci.nown : 0u, sh, &tot);
-    if (!active || ci.nown == 0) continue;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsurf) return;
+    const uint32_t meta = L.meta[i];
+    const int nown = (meta >> 24) & 15;
+    if (nown == 0) return;
+    const int64_t cell = L.cell[i];
+    uint64_t own = L.own[i];
+    const int x = (int)(cell % v.c2), y = (int)((cell / v.c2) % v.c1), z = (int)(cell / ((int64_t)v.c2 * v.c1));
     // `verts` is this volume's own array (local numbering); the index volume holds numbers of the whole mesh
-    int64_t vid = (int64_t)blk_verts[group] + pre;
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
-    unsigned seen = 0;
-    for (int k = 0; k < 3 * ci.nt; ++k) {
-        const int e = ci.row[k];
-        if (seen & (1u << e)) continue;
-        seen |= 1u << e;
+    int64_t vid = (int64_t)(blk_vt[cell >> 8] >> 32) + (meta & 0xfffu);
+    for (int j = 0; j < nown; ++j, own >>= 4, ++vid) {
+        const int e = (int)(own & 15u);
         if (e == 12) {
             double sw = 0, sx = 0, sy = 0, sz = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const double w = 1.0 / __dadd_rn(MC_EPS, fabs(ci.c[i]));
-                sx = __dadd_rn(sx, __dmul_rn(w, (double)COFF[i][0]));
-                sy = __dadd_rn(sy, __dmul_rn(w, (double)COFF[i][1]));
-                sz = __dadd_rn(sz, __dmul_rn(w, (double)COFF[i][2]));
+            for (int c = 0; c < 8; ++c) {
+                const double val = vol_at(v, z + COFF[c][2], y + COFF[c][1], x + COFF[c][0]) - v.level;
+                const double w = 1.0 / __dadd_rn(MC_EPS, fabs(val));
+                sx = __dadd_rn(sx, __dmul_rn(w, (double)COFF[c][0]));
+                sy = __dadd_rn(sy, __dmul_rn(w, (double)COFF[c][1]));
+                sz = __dadd_rn(sz, __dmul_rn(w, (double)COFF[c][2]));
                 sw = __dadd_rn(sw, w);
             }
-            verts[3 * vid + 0] = (float)__dadd_rn((double)(ci.z + v.zoff), sz / sw);
-            verts[3 * vid + 1] = (float)__dadd_rn((double)ci.y, sy / sw);
-            verts[3 * vid + 2] = (float)__dadd_rn((double)ci.x, sx / sw);
-            ++vid;
-        } else if ((EDGE_NEEDZERO[e] & ~zero_mask) == 0) {
-            const int axis = EDGE_AXIS[e];
-            const int bx = ci.x + EDGE_BASE[e][0], by = ci.y + EDGE_BASE[e][1], bz = ci.z + EDGE_BASE[e][2];
-            // lower endpoint = the corner at the base point, upper = the other one
-            const int ca = EDGE_A[e], cb = EDGE_B[e];
-            const bool a_is_lo = COFF[ca][axis] == 0;
-            const double clo = a_is_lo ? ci.c[ca] : ci.c[cb], chi = a_is_lo ? ci.c[cb] : ci.c[ca];
+            verts[3 * vid + 0] = (float)__dadd_rn((double)(z + v.zoff), sz / sw);
+            verts[3 * vid + 1] = (float)__dadd_rn((double)y, sy / sw);
+            verts[3 * vid + 2] = (float)__dadd_rn((double)x, sx / sw);
+        } else {
+            const int axis = (int)((EDGE_AXIS_BITS >> (2 * e)) & 3u);
+            const unsigned bo = (unsigned)((EDGE_BASE_BITS >> (3 * e)) & 7u);
+            const int bx = x + (int)(bo & 1u), by = y + (int)((bo >> 1) & 1u), bz = z + (int)(bo >> 2);
+            // lower endpoint = the node at the base point, upper = its neighbour along the edge's axis
+            const double clo = vol_at(v, bz, by, bx) - v.level;
+            const double chi = vol_at(v, bz + (axis == 2), by + (axis == 1), bx + (axis == 0)) - v.level;
             const double wlo = 1.0 / __dadd_rn(MC_EPS, fabs(clo)), whi = 1.0 / __dadd_rn(MC_EPS, fabs(chi));
             const double t = whi / __dadd_rn(wlo, whi);
             const int gz = bz + v.zoff;
@@ -398,93 +461,81 @@ __global__ void k_mc_verts(const Vol v, int64_t ngroups, const uint64_t *blk_ver
             verts[3 * vid + 1] = (float)(axis == 1 ? __dadd_rn((double)by, t) : (double)by);
             verts[3 * vid + 2] = (float)(axis == 0 ? __dadd_rn((double)bx, t) : (double)bx);
             edge_index[edge_slot(v, axis, bz, by, bx)] = (int32_t)(vert_base + vid);
-            ++vid;
         }
     }
-  }
 }
 
-// pass 3: triangle indices ('descent' => the three indices of every triangle are reversed)
-__global__ void k_mc_faces(const Vol v, int64_t ngroups, const uint64_t *blk_verts, const uint64_t *blk_tris, int64_t vert_base,
-                           const int32_t *edge_index, int32_t *faces)
+// pass 3: one lane per surface cell: triangle indices ('descent' => the three indices of every triangle are reversed)
+__global__ __launch_bounds__(256) void k_mc_faces(const Vol v, const SurfList L, int64_t nsurf, const uint64_t *blk_vt,
+                                                  int64_t vert_base, const int32_t *edge_index, int32_t *faces)
 {
-    __shared__ uint32_t sh[4];
-  for (int gi = 0; gi < MC_GPB; ++gi) {
-    const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
-    if (group >= ngroups) break;
-    if (!v.gflag[group]) continue;                               // block-uniform
-    const int64_t cell = group * 256 + threadIdx.x;
-    CellInfo ci;
-    bool active = false;
-    if (cell < v.ncells) active = classify(v, cell, ci);
-    uint32_t tot;
-    const uint32_t pre = block_exclusive_scan_256(active ? ((uint32_t)ci.nown | ((uint32_t)ci.nt << 16)) : 0u, sh, &tot);
-    if (!active) continue;
-    const int64_t vbase = vert_base + (int64_t)blk_verts[group] + (pre & 0xffffu);
-    int64_t f = (int64_t)blk_tris[group] + (pre >> 16);
-    // index of the centre vertex = vbase + number of owned vertices first referenced before it
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsurf) return;
+    const uint32_t meta = L.meta[i];
+    const int nt = (int)(meta >> 28), nown = (meta >> 24) & 15;
+    const int64_t cell = L.cell[i];
+    const signed char *row = L.row[i];
+    const uint64_t vt = blk_vt[cell >> 8];
+    const int x = (int)(cell % v.c2), y = (int)((cell / v.c2) % v.c1), z = (int)(cell / ((int64_t)v.c2 * v.c1));
+    // the centre vertex is the cell's own: its first vertex number + the rank of id 12 among its owned vertices
     int32_t centre = -1;
     {
-        unsigned seen = 0;
-        int rank = 0;
-        for (int k = 0; k < 3 * ci.nt; ++k) {
-            const int e = ci.row[k];
-            if (seen & (1u << e)) continue;
-            seen |= 1u << e;
-            if (e == 12) { centre = (int32_t)(vbase + rank); break; }
-            if ((EDGE_NEEDZERO[e] & ~zero_mask) == 0) ++rank;
-        }
+        uint64_t own = L.own[i];
+        for (int j = 0; j < nown; ++j, own >>= 4)
+            if ((own & 15u) == 12u) { centre = (int32_t)(vert_base + (int64_t)(vt >> 32) + (meta & 0xfffu) + j); break; }
     }
-    for (int t = 0; t < ci.nt; ++t) {
+    int64_t f = (int64_t)(vt & 0xffffffffull) + ((meta >> 12) & 0xfffu);
+    for (int t = 0; t < nt; ++t, ++f) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int e = ci.row[3 * t + k];
-            int32_t vid;
-            if (e == 12) {
-                vid = centre;
-            } else {
-                const int axis = EDGE_AXIS[e];
-                vid = edge_index[edge_slot(v, axis, ci.z + EDGE_BASE[e][2], ci.y + EDGE_BASE[e][1], ci.x + EDGE_BASE[e][0])];
+            const int e = row[3 * t + k];
+            int32_t vid = centre;
+            if (e != 12) {
+                const int axis = (int)((EDGE_AXIS_BITS >> (2 * e)) & 3u);
+                const unsigned bo = (unsigned)((EDGE_BASE_BITS >> (3 * e)) & 7u);
+                vid = edge_index[edge_slot(v, axis, z + (int)(bo >> 2), y + (int)((bo >> 1) & 1u), x + (int)(bo & 1u))];
             }
-            faces[3 * (f + t) + (2 - k)] = vid;
+            faces[3 * f + (2 - k)] = vid;
         }
     }
-  }
 }
 
 struct McArena {
-    uint64_t *blk_verts, *blk_tris, *totals, *tile_sums;
+    uint64_t *blk_vt, *totals, *tile_sums;
     float *mm;
+    uint16_t *nbflags;
     uint8_t *brick, *gflag;
+    SurfList list;
     int32_t *edge_index;
-    int64_t nblocks, nbricks;      // nblocks = groups of 256 cells
+    int64_t nblocks, nbricks, nnb;      // nblocks = groups of 256 cells; nnb = node bricks
+    int nb0, nb1, nb2;
     size_t bytes;
 };
 
-constexpr int MM_BLOCKS = 1024;
-
-// arena: [blk_verts nblocks+1][blk_tris nblocks+1][totals 2][minmax partials][scan scratch][brick map][group flags][edge_index 3*N int32]
-McArena carve(const Vol &v, char *base)
+// arena: [blk_vt nblocks+1][totals][minmax partials][scan scratch][node-brick flags][brick map][group flags][surface list][edge_index 3*N int32]
+McArena carve(const Vol &v, char *base, int64_t cap)
 {
     McArena a;
     a.nblocks = (v.ncells + 255) / 256;
     a.nbricks = (int64_t)v.b0 * v.b1 * v.b2;
-    const size_t scan_bytes = (size_t)round_up((a.nblocks + 1) * 8, 256);
-    const size_t mm_bytes = (size_t)round_up((2 * MM_BLOCKS + 2) * 4, 256);
-    const size_t tile_bytes = (size_t)round_up((scan_tiles(a.nblocks) + 1) * 8, 256);
-    const size_t brick_bytes = (size_t)round_up(a.nbricks, 256);
-    const size_t edge_bytes = (size_t)3 * v.n0 * v.n1 * v.n2 * sizeof(int32_t);
-    a.blk_verts = (uint64_t *)base;
-    a.blk_tris = (uint64_t *)(base + scan_bytes);
-    a.totals = (uint64_t *)(base + 2 * scan_bytes);
-    a.mm = (float *)(base + 2 * scan_bytes + 256);
-    a.tile_sums = (uint64_t *)(base + 2 * scan_bytes + 256 + mm_bytes);
-    const size_t gflag_bytes = (size_t)round_up(a.nblocks, 256);
-    a.brick = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes);
-    a.gflag = (uint8_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes);
-    a.edge_index = (int32_t *)(base + 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + gflag_bytes);
-    a.bytes = 2 * scan_bytes + 256 + mm_bytes + tile_bytes + brick_bytes + gflag_bytes + edge_bytes;
+    a.nb0 = (v.n0 + 7) / 8; a.nb1 = (v.n1 + 7) / 8; a.nb2 = (v.n2 + 7) / 8;
+    a.nnb = (int64_t)a.nb0 * a.nb1 * a.nb2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base + off; off += (size_t)round_up((int64_t)bytes, 256); return p; };
+    a.blk_vt = (uint64_t *)take((size_t)(a.nblocks + 1) * 8);
+    a.totals = (uint64_t *)take(256);
+    a.mm = (float *)take((size_t)(2 * (size_t)a.nb0 * a.nb1 + 2) * 4);
+    a.tile_sums = (uint64_t *)take((size_t)(scan_tiles(a.nblocks) + 1) * 8);
+    a.nbflags = (uint16_t *)take((size_t)a.nnb * 2);
+    a.brick = (uint8_t *)take((size_t)a.nbricks);
+    a.gflag = (uint8_t *)take((size_t)a.nblocks);
+    a.list.cap = cap;
+    a.list.cell = (int64_t *)take((size_t)cap * 8);
+    a.list.row = (const signed char **)take((size_t)cap * 8);
+    a.list.own = (uint64_t *)take((size_t)cap * 8);
+    a.list.meta = (uint32_t *)take((size_t)cap * 4);
+    a.edge_index = (int32_t *)take((size_t)3 * v.n0 * v.n1 * v.n2 * sizeof(int32_t));
+    a.bytes = off;
     return a;
 }
 
@@ -494,6 +545,10 @@ Vol make_vol(const void *volume, int dtype, int n0, int n1, int n2, double level
                (n0 - 1 + 7) / 8, (n1 - 1 + 7) / 8, (n2 - 1 + 7) / 8, nullptr, zoff};
 }
 
+// first guess of the list capacity: one cell in 16 on the surface (a 512^3 body has ~1 in 500, the roughest synthetic field of
+// the bench 1 in 30); a volume that needs more reruns the counting pass once with the exact number
+int64_t initial_list_cap(const Vol &v) { return std::max<int64_t>(1 << 16, v.ncells / 16); }
+
 // counting half, shared by the whole-volume and the slab entry points: totals and the value range on the host
 int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level, int zoff,
                   uint64_t *nv, uint64_t *nf, float *lo, float *hi, hipStream_t st)
@@ -501,38 +556,57 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
     PIFU_HIP(hipSetDevice(ctx->device));
     ctx->mc.valid = false;
     Vol v = make_vol(volume, dtype, n0, n1, n2, level, zoff);
-    McArena a = carve(v, nullptr);
-    int rc = pifu_ensure(ctx->mc_arena, a.bytes);
-    if (rc) return rc;
-    a = carve(v, (char *)ctx->mc_arena.p);
+    // the list keeps the capacity an earlier, rougher volume needed (bounded by this volume's cell count)
+    int64_t cap = std::min<int64_t>(std::max<int64_t>(initial_list_cap(v), ctx->mc.list_cap), v.ncells);
     hipEvent_t prof_stop;
-    rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
+    int rc = pifu_prof_begin(ctx, PIFU_PROF_MC, st, &prof_stop);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mc_bricks, dim3((unsigned)((a.nbricks + 3) / 4)), dim3(256), 0, st, v, a.brick);
-    v.brick = a.brick;
-    hipLaunchKernelGGL(k_mc_minmax, dim3(MM_BLOCKS), dim3(256), 0, st, v, a.mm + 2);
-    hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), MM_BLOCKS, a.mm);
-    hipLaunchKernelGGL(k_mc_groups, dim3((unsigned)((a.nblocks + 255) / 256)), dim3(256), 0, st, v, a.nblocks, a.gflag);
-    v.gflag = a.gflag;
-    hipLaunchKernelGGL(k_mc_count, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks, a.blk_verts,
-                       a.blk_tris);
-    scan_u64(a.blk_verts, a.nblocks, a.totals, a.tile_sums, st);
-    scan_u64(a.blk_tris, a.nblocks, a.totals + 1, a.tile_sums, st);      // stream order: the scratch is free again
+    uint64_t nsurf = 0;
+    for (int attempt = 0;; ++attempt) {
+        McArena a = carve(v, nullptr, cap);
+        rc = pifu_ensure(ctx->mc_arena, a.bytes);
+        if (rc) return rc;
+        a = carve(v, (char *)ctx->mc_arena.p, cap);
+        const int npencils = a.nb0 * a.nb1;
+        v.brick = nullptr; v.gflag = nullptr;
+        hipLaunchKernelGGL(k_mc_nodebricks, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
+        hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), npencils, a.mm);
+        hipLaunchKernelGGL(k_mc_brick_combine, dim3((unsigned)((a.nbricks + 255) / 256)), dim3(256), 0, st, v, a.nb0, a.nb1, a.nb2,
+                           (const uint16_t *)a.nbflags, a.brick);
+        v.brick = a.brick;
+        hipLaunchKernelGGL(k_mc_groups, dim3((unsigned)((a.nblocks + 255) / 256)), dim3(256), 0, st, v, a.nblocks, a.gflag);
+        v.gflag = a.gflag;
+        PIFU_HIP(hipMemsetAsync(a.totals, 0, 32, st));
+        hipLaunchKernelGGL(k_mc_count, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks, a.blk_vt,
+                           a.list, (unsigned long long *)(a.totals + 2));
+        scan_u64(a.blk_vt, a.nblocks, a.totals, a.tile_sums, st);
+        char *pin = (char *)ctx->pinned;
+        PIFU_HIP(hipMemcpyAsync(pin, a.totals, 24, hipMemcpyDeviceToHost, st));
+        PIFU_HIP(hipMemcpyAsync(pin + 24, a.mm, 8, hipMemcpyDeviceToHost, st));
+        PIFU_HIP(hipStreamSynchronize(st));
+        const uint64_t vt = ((uint64_t *)pin)[0];
+        *nv = vt >> 32;
+        *nf = vt & 0xffffffffull;
+        nsurf = ((uint64_t *)pin)[2];
+        *lo = ((float *)(pin + 24))[0];
+        *hi = ((float *)(pin + 24))[1];
+        // (vertices << 32 | triangles) sums carry no bit across the halves as long as the triangles stay below 2^32
+        PIFU_REQUIRE(nsurf * 12ull < (1ull << 32), PIFU_ERR_INVALID, "marching cubes: %llu surface cells are more than the 32-bit "
+                     "triangle numbering holds", (unsigned long long)nsurf);
+        if ((int64_t)nsurf <= cap) break;
+        // more surface cells than the list holds (every one was counted, the surplus not recorded): make room for exactly
+        // that many and run the counting half again (the arena sections behind the list move with the capacity)
+        PIFU_REQUIRE(attempt == 0, PIFU_ERR_STATE, "marching cubes: surface list overflow after resizing");
+        cap = (int64_t)nsurf;
+    }
     // timed: the counting half; work = one pass over the volume (the floor of any marching cubes: every sample is read once)
     rc = pifu_prof_end(ctx, PIFU_PROF_MC, prof_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
     if (rc) return rc;
-    char *pin = (char *)ctx->pinned;
-    PIFU_HIP(hipMemcpyAsync(pin, a.totals, 16, hipMemcpyDeviceToHost, st));
-    PIFU_HIP(hipMemcpyAsync(pin + 16, a.mm, 8, hipMemcpyDeviceToHost, st));
-    PIFU_HIP(hipStreamSynchronize(st));
-    *nv = ((uint64_t *)pin)[0];
-    *nf = ((uint64_t *)pin)[1];
-    *lo = ((float *)(pin + 16))[0];
-    *hi = ((float *)(pin + 16))[1];
     McState &m = ctx->mc;
     m.n0 = n0; m.n1 = n1; m.n2 = n2;
     m.level = level; m.dtype = dtype; m.volume = volume; m.zoff = zoff;
     m.nverts = (int64_t)*nv; m.nfaces = (int64_t)*nf;
+    m.nsurf = (int64_t)nsurf; m.list_cap = cap;
     m.verts_done = false;
     m.vert_base = 0;
     return PIFU_OK;
@@ -542,11 +616,10 @@ int mc_verts_impl(pifu_ctx *ctx, float *verts, int64_t vert_base, hipStream_t st
 {
     McState &m = ctx->mc;
     Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
-    const McArena a = carve(v, (char *)ctx->mc_arena.p);
-    v.brick = a.brick;                                                        // built by the counting half for this volume
-    v.gflag = a.gflag;
-    hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks,
-                       (const uint64_t *)a.blk_verts, vert_base, verts, a.edge_index);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p, m.list_cap);
+    if (m.nsurf > 0)
+        hipLaunchKernelGGL(k_mc_verts, dim3((unsigned)((m.nsurf + 255) / 256)), dim3(256), 0, st, v, a.list, m.nsurf,
+                           (const uint64_t *)a.blk_vt, vert_base, verts, a.edge_index);
     m.verts_done = true;
     m.vert_base = vert_base;
     return PIFU_OK;
@@ -556,11 +629,10 @@ int mc_faces_impl(pifu_ctx *ctx, int32_t *faces, hipStream_t st)
 {
     McState &m = ctx->mc;
     Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
-    const McArena a = carve(v, (char *)ctx->mc_arena.p);
-    v.brick = a.brick;
-    v.gflag = a.gflag;
-    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks,
-                       (const uint64_t *)a.blk_verts, (const uint64_t *)a.blk_tris, m.vert_base, (const int32_t *)a.edge_index, faces);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p, m.list_cap);
+    if (m.nsurf > 0)
+        hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)((m.nsurf + 255) / 256)), dim3(256), 0, st, v, a.list, m.nsurf,
+                           (const uint64_t *)a.blk_vt, m.vert_base, (const int32_t *)a.edge_index, faces);
     return PIFU_OK;
 }
 
@@ -569,7 +641,7 @@ int32_t *edge_plane(pifu_ctx *ctx, int axis, int z)
 {
     const McState &m = ctx->mc;
     Vol v = make_vol(m.volume, m.dtype, m.n0, m.n1, m.n2, m.level, m.zoff);
-    const McArena a = carve(v, (char *)ctx->mc_arena.p);
+    const McArena a = carve(v, (char *)ctx->mc_arena.p, m.list_cap);
     return a.edge_index + (size_t)axis * m.n0 * m.n1 * m.n2 + (size_t)z * m.n1 * m.n2;
 }
 

@@ -92,8 +92,10 @@ __global__ void k_cc_label(const int32_t *faces, int64_t nfaces, const unsigned 
         const unsigned long long key = edge_key(v[e], v[(e + 1) % 3]);
         unsigned h = edge_hash(key, mask);
         while (keys[h] != key) h = (h + 1) & mask;
-        if (cnt[h] != 2) o = 1;
-    }
+        const int c = cnt[h];
+        if (c == 1) o |= 1;              // an edge only this face uses: the component is open whatever else it holds
+        else if (c != 2) o |= 2;         // an edge three or more faces share: no adjacency through it; whether it pairs up
+    }                                    // INSIDE a component is the caller's to decide (it knows the labels)
     open[f] = o;
 }
 

@@ -93,6 +93,7 @@ struct McState {
     int dtype = 0;
     const void *volume = nullptr;
     int64_t nverts = 0, nfaces = 0;
+    int64_t nsurf = 0, list_cap = 0;      // surface-cell records written by the counting pass, and the list's capacity
     // slab mode (pifu_mc_slab_*): first node plane of the slab in the tall volume, numbering offset of its vertices
     bool slab = false, verts_done = false;
     int zoff = 0;

@@ -187,10 +187,35 @@ def read_obj_with_color(path):
     return va[:, :3].copy(), va[:, 3:6].copy(), np.asarray(f, dtype=np.int64).reshape(-1, 3).astype(np.int32) - 1
 
 
+def merge_vertices(verts, colours, faces):
+    """What `trimesh.load(obj_path)` does before `split()` sees the mesh (`reconstruction.py:332`; default `process=True`
+    -> `merge_vertices`): referenced vertices with the same position become ONE vertex - the OBJ carries 4 decimals, so the
+    marching-cubes vertices next to a grid node coincide after the round trip, hundreds of times per 512^3 mesh - the
+    first occurrence survives with its colour, survivors keep their file order, unreferenced vertices go, faces are
+    re-indexed and NOT filtered (triangles that become degenerate stay: `validate=False`).  trimesh is absent from this
+    image: restated from its published behaviour (positions compared after rounding to 8 decimals), parity unpinned."""
+    faces = np.asarray(faces)
+    referenced = np.zeros(len(verts), dtype=bool)
+    referenced[faces.reshape(-1)] = True
+    ref = np.flatnonzero(referenced)
+    keys = np.round(verts[ref] * 1e8).astype(np.int64)
+    _, first, inverse = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind='stable')                     # unique rows come sorted by value: back to file order
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    remap = np.full(len(verts), -1, dtype=np.int64)
+    remap[ref] = rank[np.asarray(inverse).reshape(-1)]
+    kept = ref[first[order]]
+    return verts[kept], colours[kept], remap[faces].astype(np.int32)
+
+
 def largest_component(verts, faces, device):
     """Face indices (ascending) of the component `meshcleaning` keeps (`reconstruction.py:331-342`): of the WATERTIGHT
     edge-connected components (trimesh's `mesh.split()` default), the one with the largest extent along axis 0; the first
-    one wins ties.  Components come from the device union-find `pifu_face_components`.  Raises IndexError when no
+    one wins ties.  Components come from the device union-find `pifu_face_components` (faces adjacent iff they share an
+    edge exactly two faces use).  Watertight is judged per component, as trimesh judges each sub-mesh: a face flagged
+    for an edge nobody else uses opens its component; the faces around an edge that three or more faces share (they
+    appear once vertices have been merged) are few and are counted per component here.  Raises IndexError when no
     component is watertight (`cc[0]` on an empty list in the reference)."""
     import ctypes as C
 
@@ -203,10 +228,23 @@ def largest_component(verts, faces, device):
     label = torch.empty(len(faces), device=ctx.device, dtype=torch.int32)
     open_edge = torch.empty(len(faces), device=ctx.device, dtype=torch.uint8)
     _lib.call('pifu_face_components', ctx.h, _ptr(fd), len(faces), _ptr(label), _ptr(open_edge), _stream_ptr(ctx.device))
-    label, open_edge = label.cpu().numpy(), open_edge.cpu().numpy().astype(bool)
+    label, flag = label.cpu().numpy(), open_edge.cpu().numpy()
     roots, inv = np.unique(label, return_inverse=True)            # ascending root = ascending first face: trimesh's order
     leaky = np.zeros(len(roots), bool)
-    np.logical_or.at(leaky, inv, open_edge)
+    np.logical_or.at(leaky, inv, (flag & 1) != 0)
+    shared = np.flatnonzero(flag & 2)                             # every face around a 3+-face edge carries the bit
+    if len(shared):
+        f = np.asarray(faces, dtype=np.int64)[shared]
+        a = np.concatenate([f[:, 0], f[:, 1], f[:, 2]])
+        b = np.concatenate([f[:, 1], f[:, 2], f[:, 0]])
+        comp = np.tile(inv[shared], 3)
+        rows = np.stack([np.minimum(a, b), np.maximum(a, b)], 1)
+        _, e_inv, e_cnt = np.unique(rows, axis=0, return_inverse=True, return_counts=True)
+        crowded = e_cnt[np.asarray(e_inv).reshape(-1)] >= 3       # the other edges of these faces are ordinary ones
+        _, ec_inv, ec_cnt = np.unique(np.concatenate([rows[crowded], comp[crowded, None]], 1), axis=0, return_inverse=True,
+                                      return_counts=True)
+        odd = ec_cnt[np.asarray(ec_inv).reshape(-1)] != 2          # inside its component the edge does not pair up
+        leaky[comp[crowded][odd]] = True
     x = verts[:, 0][faces]                                       # [F, 3]
     lo = np.full(len(roots), np.inf)
     hi = np.full(len(roots), -np.inf)
@@ -224,12 +262,14 @@ def largest_component(verts, faces, device):
 
 def meshcleaning(obj_path, device='cuda'):
     """`meshcleaning` (`reconstruction.py:325-344`): keep the connected component with the largest extent along axis 0
-    and rewrite the file.  The OBJ is read back as written (4 decimals), vertices no face of the component references are
-    dropped (order kept), faces keep their file order.  Returns (verts, colours uint8 RGBA, faces) of the kept component;
-    colours take trimesh's float -> uint8 route (round(c * 255), alpha 255) - trimesh is absent here, so its loader's
-    behaviour is restated, not pinned."""
+    and rewrite the file.  The OBJ is read back as written (4 decimals) and vertices at the same position are merged, as
+    trimesh's loader does (`merge_vertices`); vertices no face of the kept component references are dropped (order kept),
+    faces keep their file order.  Returns (verts, colours uint8 RGBA, faces) of the kept component; colours take trimesh's
+    float -> uint8 route (round(c * 255), alpha 255) - trimesh is absent here, so its loader's behaviour is restated, not
+    pinned."""
     print(f'Processing mesh cleaning: {obj_path}')
     verts, colours, faces = read_obj_with_color(obj_path)
+    verts, colours, faces = merge_vertices(verts, colours, faces)
     keep = largest_component(verts, faces, device)
     used = np.unique(faces[keep])
     remap = np.full(len(verts), -1, np.int64)

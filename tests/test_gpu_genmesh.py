@@ -239,21 +239,15 @@ def _plus_oracle(base_obj, calib):
     from oracle import pifu_oracle as O
     from pifuhd_amd import reconstruction
     v0, c0, f0 = reconstruction.read_obj_with_color(base_obj)
-    lab, open_face = O.face_components(f0)
-    best, best_ext = None, None
-    for r in np.unique(lab):
-        sel = lab == r
-        if open_face[sel].any():
-            continue
-        ext = np.ptp(v0[:, 0][f0[sel]])
-        if best is None or best_ext < ext:
-            best, best_ext = r, ext
-    if best is None:
-        return IndexError('list index out of range')
-    used = np.unique(f0[lab == best])
+    v0, c0, f0 = O.merge_vertices(v0, c0, f0)                     # trimesh.load(process=True)
+    try:
+        keep = O.widest_watertight_component(v0, f0)               # mesh.split() + the extent loop
+    except IndexError as e:
+        return e
+    used = np.unique(f0[keep])
     remap = np.full(len(v0), -1)
     remap[used] = np.arange(len(used))
-    verts, faces = v0[used], remap[f0[lab == best]]
+    verts, faces = v0[used], remap[f0[keep]]
     rgba0 = np.concatenate([np.clip(np.rint(c0[used] * 255.0), 0, 255), np.full((len(used), 1), 255.0)], 1).astype(np.uint16)
     xyz = O.orthogonal(torch.from_numpy(verts.T).float()[None], calib)[0].numpy().T
     try:
@@ -300,6 +294,49 @@ def test_meshcleaning_and_recolouring_on_analytic_bodies(tmp_path):
     mesh_util.save_obj_mesh_with_color(only_sheet, v.cpu().numpy().astype(np.float64), f.cpu().numpy(), np.zeros((len(v), 3)))
     with pytest.raises(IndexError):
         reconstruction.meshcleaning(only_sheet, 'cuda')
+
+
+def test_meshcleaning_merges_coincident_vertices_like_the_trimesh_loader(tmp_path):
+    """`trimesh.load` merges vertices that share a position before `split()` runs, and the OBJ carries 4 decimals: the
+    marching-cubes vertices around a grid node whose value all but equals the level coincide after the round trip.  The
+    merge leaves degenerate triangles behind (kept: validate=False), so the body that owns them is no longer watertight
+    and `split()` drops it.  Here that happens to the WIDE ellipsoid: the taller, narrower one must be kept - by the
+    product exactly as by the restated pipeline of the oracle."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util, reconstruction
+    from pifuhd_amd.nets import _Ctx
+    R = 64
+    lin = -1 + 2 * np.arange(R) / R
+    X, Y, Z = np.meshgrid(lin, lin, lin, indexing='ij')
+    wide = 1 - np.sqrt(((X + 0.1) / 0.55) ** 2 + ((Y - 0.45) / 0.2) ** 2 + (Z / 0.3) ** 2)
+    tall = 1 - np.sqrt(((X - 0.3) / 0.2) ** 2 + ((Y + 0.35) / 0.4) ** 2 + (Z / 0.25) ** 2)
+    vol = (0.5 + 0.5 * np.maximum(wide, tall)).astype(np.float32)
+    # a node of the wide body's surface shell gets a value a hair above the level: every crossing on its edges lands within
+    # 1e-6 of the node, and 4 decimals cannot tell them apart
+    shell = np.argwhere((np.abs(vol - 0.5) < 0.02) & (Y > 0.2))
+    node = tuple(shell[len(shell) // 2])
+    vol[node] = np.float32(0.5 + 2e-7)
+    v, f = mesh_util.marching_cubes_device(_Ctx('cuda'), torch.from_numpy(vol).cuda(), 0.5)
+    verts = v.cpu().numpy().astype(np.float64) * (2.0 / R) - 1.0
+    faces = f.cpu().numpy()
+    colour = np.random.RandomState(5).rand(len(verts), 3)
+    base = str(tmp_path / 'coincident.obj')
+    mesh_util.save_obj_mesh_with_color(base, verts, faces, colour)
+    v0, c0, f0 = reconstruction.read_obj_with_color(base)
+    assert len(np.unique(v0, axis=0)) < len(v0)                                   # the file really holds coincident vertices
+    mv, mc, mf = reconstruction.merge_vertices(v0, c0, f0)
+    ov, oc_, of_ = O.merge_vertices(v0, c0, f0)
+    assert np.array_equal(mv, ov) and np.array_equal(mc, oc_) and np.array_equal(mf, of_)
+    assert len(mv) < len(v0) and len(mf) == len(f0)                               # merged; no face dropped
+    assert ((mf[:, 0] == mf[:, 1]) | (mf[:, 1] == mf[:, 2]) | (mf[:, 0] == mf[:, 2])).any()      # degenerate ones stay
+    want = _plus_oracle(base, calib_tensor())
+    assert not isinstance(want, Exception)
+    kept_v, kept_rgba, kept_f = reconstruction.meshcleaning(base, 'cuda')
+    assert np.array_equal(kept_v, want[0]) and np.array_equal(kept_f, want[1])
+    assert kept_v[:, 1].max() < 0.2 and np.ptp(kept_v[:, 0]) < 0.5                # the tall body: the wide one stopped being watertight
+    # the component test itself against the serial restatement, on the merged mesh
+    keep = reconstruction.largest_component(mv, mf, 'cuda')
+    assert np.array_equal(keep, O.widest_watertight_component(mv, mf))
 
 
 def test_gen_mesh_imgcolor_plus(tmp_path, capsys):

@@ -34,3 +34,37 @@ def test_face_components_oracle():
     label, open_face = O.face_components(faces)
     assert list(label) == [0, 0, 0, 0, 4, 4, 4, 4, 8]
     assert list(open_face) == [0] * 8 + [1]
+
+
+def test_merge_vertices_host_logic_matches_the_oracle_restatement():
+    """`merge_vertices` (what trimesh's loader does before `split()`): first occurrence kept with its colour, file order
+    kept, unreferenced vertices dropped, faces re-indexed and never filtered - product host code against the oracle's
+    dictionary-based restatement, on positions with many coincidences."""
+    import numpy as np
+    import pifuhd_amd  # noqa: F401
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import reconstruction
+    rs = np.random.RandomState(0)
+    v = np.round(rs.randint(-5, 5, size=(300, 3)) / 10.0, 4).astype(np.float64)
+    c = rs.rand(300, 3)
+    f = rs.randint(0, 280, size=(500, 3)).astype(np.int32)                      # vertices 280.. are unreferenced
+    got, want = reconstruction.merge_vertices(v, c, f), O.merge_vertices(v, c, f)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    mv, mc, mf = got
+    assert len(mv) == len(np.unique(v[np.unique(f)], axis=0)) and len(mf) == len(f)
+    assert np.array_equal(mv[mf], v[f])                                          # every face still sits where it sat
+    ref = np.unique(f)
+    first = [int(ref[np.flatnonzero((v[ref] == p).all(1))[0]]) for p in mv]      # first REFERENCED occurrence
+    assert first == sorted(first) and np.array_equal(mc, c[first])               # file order, first occurrence's colour
+    # the serial component selection: two tetrahedra that share ONE EDGE (0, 1).  Four faces of the whole mesh use it, so it
+    # gives no adjacency; each tetrahedron hangs together through its other edges and, on its own, uses the edge exactly
+    # twice - both are watertight sub-meshes for trimesh, and the one with the larger x extent (the second) is kept
+    def tet(a, b, c, d):
+        return [[a, b, c], [a, d, b], [b, d, c], [c, d, a]]
+    verts = np.array([[0, 0, 0], [0, 0, 1], [1, 0, 0], [0, 1, 0], [-2, 1, 0], [-2, -1, 0.5]], dtype=np.float64)
+    faces = np.array(tet(0, 1, 2, 3) + tet(0, 1, 4, 5))
+    lab, flagged = O.face_components(faces)
+    assert sorted(set(lab)) == [0, 4] and list(flagged) == [1, 1, 0, 0, 1, 1, 0, 0]  # the faces around the 4-face edge
+    assert np.array_equal(O.widest_watertight_component(verts, faces), [4, 5, 6, 7])
+    # open it: without one face the second tetrahedron is no longer watertight and the first one is kept
+    assert np.array_equal(O.widest_watertight_component(verts, faces[:7]), [0, 1, 2, 3])

@@ -1,15 +1,28 @@
 #!/bin/bash
-# per-kernel time of marching cubes on a smooth and a noisy 512^3 volume (tools/mc_time.py under rocprofv3)
+# Marching cubes, per kernel, on a smooth and a noisy R^3 volume (tools/mc_time.py): kernel trace + three PMC passes
+# (SQ_WAVE_CYCLES SQ_BUSY_CYCLES | FETCH_SIZE | WRITE_SIZE, each its own run as the pool requires), for the current library
+# and for the round-2 build (tools/lab/r02/libpifuhd_hip_r02.so) when it is present.  Summary -> gpurun_out/mc_prof_R.txt
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/mcprof; rm -rf $OUT
-cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $ROOT/tools/mc_time.py ${1:-512} > $OUT.txt 2>&1
-cd $ROOT; grep "\^3" $OUT.txt
-python - <<'P'
-import csv, glob
-f = sorted(glob.glob("gpurun_out/mcprof/*/*_kernel_stats.csv"))[-1]
-for i, r in enumerate(csv.DictReader(open(f))):
-    if i >= 14: break
-    print("%-34s calls %4s avg_us %8.1f min %8.1f max %8.1f" % (r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:34], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3))
-P
-rm -rf $OUT
+R=${1:-512}
+SUM=$ROOT/gpurun_out/mc_prof_$R.txt
+mkdir -p $ROOT/gpurun_out; : > $SUM
+for which in now r02; do
+    LIBARG=""
+    if [ $which = r02 ]; then
+        [ -f $ROOT/tools/lab/r02/libpifuhd_hip_r02.so ] || continue
+        LIBARG="--lib $ROOT/tools/lab/r02/libpifuhd_hip_r02.so"
+    fi
+    OUT=$ROOT/gpurun_out/mcprof_$which; rm -rf $OUT; mkdir -p $OUT
+    cd /tmp
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/tools/mc_time.py $R $LIBARG > $OUT/trace.txt 2>&1 || exit 1
+    timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -- python $ROOT/tools/mc_time.py $R $LIBARG > $OUT/sq.txt 2>&1 || exit 1
+    timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $ROOT/tools/mc_time.py $R $LIBARG > $OUT/fetch.txt 2>&1 || exit 1
+    timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python $ROOT/tools/mc_time.py $R $LIBARG > $OUT/write.txt 2>&1 || exit 1
+    cd $ROOT
+    echo "== library: $which ==" >> $SUM
+    grep "\^3" $OUT/trace.txt >> $SUM
+    python tools/mc_prof_summary.py $OUT >> $SUM
+    rm -rf $OUT
+done
+cat $SUM

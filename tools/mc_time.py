@@ -3,7 +3,11 @@ import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pifuhd_amd
-from pifuhd_amd import mesh_util
+from pifuhd_amd import _lib, mesh_util
+if '--lib' in sys.argv:          # time another build of the library (tools/lab/r02: the round-2 kernels, for before / after)
+    i = sys.argv.index('--lib')
+    _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 from pifuhd_amd.nets import _Ctx
 ctx = _Ctx('cuda')
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
