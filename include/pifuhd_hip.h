@@ -58,6 +58,18 @@ enum {
                                               in z inside a column; same result up to fp32 rounding) */
 };
 
+/* pifu_filter_coarse flags */
+enum {
+    PIFU_ENC_ALL_STACKS = 1,               /* feat_nchw receives every stack's output (the module in train mode keeps the
+                                              whole list, PIFuNetwNML.py:94-97) instead of the last one */
+    PIFU_ENC_DEFER_JOIN = 2                /* return while the coarse hourglass is still running on a stream of the library:
+                                              pifu_filter_fine - which reads the normal maps, not the coarse features -
+                                              then runs beside it.  The caller's stream is made to wait for the hourglass by
+                                              the next call that needs its result (pifu_filter_fine at its end, every query /
+                                              grid entry point, pifu_set_features, the next pifu_filter_coarse); until then
+                                              feat_nchw must not be read by anyone else */
+};
+
 const char *pifu_last_error(void);
 int pifu_abi_version(void);
 
@@ -102,15 +114,16 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
  * pifu_filter_coarse = PIFuNetwNML.filter (PIFuNetwNML.py:73-97): img device NCHW [1][Cimg][H][W]; runs netF / netB
  * (networks.py:131-207) when enabled and writes their NCHW [1][3][H][W] outputs, then the HGFilter
  * (Filter.py:186-228) on cat[img, nmlF, nmlB]; the LAST stack's output becomes the coarse query feature map and is
- * optionally exported as NCHW [1][hg_dim][H/4][W/4] (ave_pool) to feat_nchw; with all_stacks != 0 (the module in train
- * mode keeps the whole list, PIFuNetwNML.py:94-97) feat_nchw receives every stack's output, [num_stack][hg_dim][H/4][W/4].
+ * optionally exported as NCHW [1][hg_dim][H/4][W/4] (ave_pool) to feat_nchw; with PIFU_ENC_ALL_STACKS in `flags`
+ * feat_nchw receives every stack's output, [num_stack][hg_dim][H/4][W/4].  The two normal nets run side by side on two
+ * streams, the hourglass on a third (joined before the call returns unless PIFU_ENC_DEFER_JOIN is given).
  * pifu_filter_fine = PIFuMRNet.filter_local (PIFuMRNet.py:83-118, rect = None): normals (NCHW, Hn x Wn) are
  * resized bilinearly (align_corners) to H x W, concatenated, HGFilter('no_down'); output [1][hg_dim][H/2][W/2]. */
 int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
 int pifu_enc_clear(pifu_ctx *ctx);
 int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                        int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
-                       float *feat_nchw, int all_stacks, pifu_stream stream);
+                       float *feat_nchw, int flags, pifu_stream stream);
 int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF,
                      const float *nmlB, int Hn, int Wn, int num_stack, int hg_depth, int hg_dim, int norm,
                      float *feat_nchw, pifu_stream stream);

@@ -16,6 +16,7 @@ LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
 PROF_GEMM, PROF_SAMPLER, PROF_MC = 0, 1, 2
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
+ENC_ALL_STACKS, ENC_DEFER_JOIN = 1, 2
 
 
 class PifuError(RuntimeError):

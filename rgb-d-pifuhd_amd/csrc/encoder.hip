@@ -663,14 +663,26 @@ struct HostParam {
     std::vector<int64_t> shape;
 };
 
-struct EncState {
-    std::map<std::string, HostParam> params;
-    std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
-    DevBuf arena;
+// A lane = one in-order chain of launches with the buffers only it touches.  Nets that do not depend on each other run in
+// different lanes, i.e. on different streams at the same time: the two normal nets (netF || netB), and - when the caller
+// lets the coarse call return before its hourglass has finished (PIFU_ENC_DEFER_JOIN) - the coarse hourglass beside the
+// fine level's, whose big grids leave room for the coarse level's small ones.
+struct Lane {
+    DevBuf arena;                                // activations (bump-allocated per call)
     DevBuf splitk;                               // partial tiles of split-K convolutions (reused, stream-ordered)
     DevBuf prep;                                 // activated + padded input of the convolution in flight (k_prep_act)
     size_t used = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;                    // lane 0: the caller's stream; lanes 1, 2: streams of the library
+    hipStream_t own = nullptr;
+};
+
+struct EncState {
+    std::map<std::string, HostParam> params;
+    std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
+    Lane lanes[3];
+    Lane *cur = &lanes[0];                       // the lane the host routine is currently issuing into
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_coarse = nullptr;
+    bool coarse_pending = false;                 // the deferred coarse hourglass has been issued and not yet joined
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
     std::string err;
@@ -692,9 +704,9 @@ struct Fail {
 float *arena_take(EncState &S, size_t floats)
 {
     const size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
-    if (S.used + bytes > S.arena.bytes) throw Fail{"encoder arena exhausted"};
-    float *p = reinterpret_cast<float *>(static_cast<char *>(S.arena.p) + S.used);
-    S.used += bytes;
+    if (S.cur->used + bytes > S.cur->arena.bytes) throw Fail{"encoder arena exhausted"};
+    float *p = reinterpret_cast<float *>(static_cast<char *>(S.cur->arena.p) + S.cur->used);
+    S.cur->used += bytes;
     return p;
 }
 
@@ -787,7 +799,7 @@ Affine norm_affine(EncState &S, const std::string &prefix, Tensor &x, int norm)
         int rows_per_block = stat_rows_per_block(P);
         nb = (P + rows_per_block - 1) / rows_per_block;
         partial = reinterpret_cast<double *>(arena_take(S, (size_t)nb * C * 2 * 2));
-        hipLaunchKernelGGL(k_channel_stats, dim3(nb), dim3(stat_threads(C)), 0, S.st, (const float *)x.p, x.ld, C, P, rows_per_block, partial);
+        hipLaunchKernelGGL(k_channel_stats, dim3(nb), dim3(stat_threads(C)), 0, S.cur->st, (const float *)x.p, x.ld, C, P, rows_per_block, partial);
         x.stat = partial;           // a second norm of the same tensor (ConvBlock bn1 / bn4) reuses the reduction
         x.stat_nb = nb;
     }
@@ -797,7 +809,7 @@ Affine norm_affine(EncState &S, const std::string &prefix, Tensor &x, int norm)
         gamma = dev_upload(S, prefix + ".weight", param(S, prefix + ".weight").data);
         beta = dev_upload(S, prefix + ".bias", param(S, prefix + ".bias").data);
     }
-    hipLaunchKernelGGL(k_stats_finalize, dim3(nblk((size_t)groups * 64, 256)), dim3(256), 0, S.st, (const double *)partial, nb, C,
+    hipLaunchKernelGGL(k_stats_finalize, dim3(nblk((size_t)groups * 64, 256)), dim3(256), 0, S.cur->st, (const double *)partial, nb, C,
                        cpg, groups, (double)P, gamma, beta, 1e-5f, sc, sh);
     a.scale = sc;
     a.shift = sh;
@@ -874,14 +886,14 @@ float *prepare_input(EncState &S, const Tensor &x, const Affine &act, int Cp, in
 {
     const size_t floats = (size_t)Hp * Wp * Cp + 64;
     if (floats * sizeof(float) >= ((size_t)1 << 32)) throw Fail{"prepared conv input exceeds 4 GB"};
-    if (pifu_ensure(S.prep, floats * sizeof(float)) != PIFU_OK) throw Fail{"prepared conv input allocation failed"};
+    if (pifu_ensure(S.cur->prep, floats * sizeof(float)) != PIFU_OK) throw Fail{"prepared conv input allocation failed"};
     PrepArgs p{};
     p.X = x.p; p.H = x.H; p.W = x.W; p.ldx = x.ld;
     p.scale = act.scale; p.shift = act.shift; p.slope = act.slope;
     p.pad_lo = pad_lo; p.reflect = reflect ? 1 : 0;
-    p.P = static_cast<float *>(S.prep.p); p.Hp = Hp; p.Wp = Wp; p.Cp = Cp;
+    p.P = static_cast<float *>(S.cur->prep.p); p.Hp = Hp; p.Wp = Wp; p.Cp = Cp;
     const size_t threads = (size_t)Hp * Wp * (Cp / 4) + 16;
-    hipLaunchKernelGGL(k_prep_act, dim3(nblk(threads, 256)), dim3(256), 0, S.st, p);
+    hipLaunchKernelGGL(k_prep_act, dim3(nblk(threads, 256)), dim3(256), 0, S.cur->st, p);
     *bytes_out = (unsigned)(floats * sizeof(float));
     return p.P;
 }
@@ -908,8 +920,8 @@ void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr,
     a.part = nullptr;
     if (nsplit > 1) {
         const size_t bytes = (size_t)nsplit * a.ntm * BM * a.ldp * sizeof(float);
-        if (pifu_ensure(S.splitk, bytes) != PIFU_OK) throw Fail{"split-K workspace allocation failed"};
-        a.part = static_cast<float *>(S.splitk.p);
+        if (pifu_ensure(S.cur->splitk, bytes) != PIFU_OK) throw Fail{"split-K workspace allocation failed"};
+        a.part = static_cast<float *>(S.cur->splitk.p);
     }
     a.stat = nullptr;
     a.stat_tile0 = 0;
@@ -925,11 +937,11 @@ void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr,
         stat->stat_nb = 0;
     }
     const unsigned grid = (unsigned)tiles * nsplit;
-    if (tn == 64) hipLaunchKernelGGL(k_conv_dma<64>, dim3(grid), dim3(256), 0, S.st, a);
-    else hipLaunchKernelGGL(k_conv_dma<32>, dim3(grid), dim3(256), 0, S.st, a);
+    if (tn == 64) hipLaunchKernelGGL(k_conv_dma<64>, dim3(grid), dim3(256), 0, S.cur->st, a);
+    else hipLaunchKernelGGL(k_conv_dma<32>, dim3(grid), dim3(256), 0, S.cur->st, a);
     if (nsplit > 1) {
         const size_t threads = (size_t)a.nrows * (a.ldp / 4);
-        hipLaunchKernelGGL(k_conv_dma_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.st, a);
+        hipLaunchKernelGGL(k_conv_dma_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.cur->st, a);
     }
 }
 
@@ -1034,13 +1046,13 @@ Tensor conv_block(EncState &S, const std::string &p, Tensor x, int cout)
         Affine a4 = norm_affine(S, p + ".bn4", x, S.norm); a4.slope = 0.f;      // same statistics as bn1: reduced once
         conv2d(S, p + ".downsample.2.weight", "", x, a4, g1, out, &out);      // out = conv1x1(...) + cat (in place)
     } else if (S.norm == 0) {       // eval-mode BatchNorm: nobody needs statistics of the sum
-        hipLaunchKernelGGL(k_add, dim3(nblk(out.pixels() * (cout / 4), 256)), dim3(256), 0, S.st, (const float *)out.p, out.ld,
+        hipLaunchKernelGGL(k_add, dim3(nblk(out.pixels() * (cout / 4), 256)), dim3(256), 0, S.cur->st, (const float *)out.p, out.ld,
                            (const float *)x.p, x.ld, (const float *)nullptr, (const float *)nullptr, out.p, out.ld, cout, out.pixels());
     } else {                        // the next block normalises this sum: leave its statistics behind
         const int P = (int)out.pixels(), rows_per_block = stat_rows_per_block(P);
         out.stat_nb = (P + rows_per_block - 1) / rows_per_block;
         out.stat = reinterpret_cast<double *>(arena_take(S, (size_t)out.stat_nb * cout * 2 * 2));
-        hipLaunchKernelGGL(k_add_stats, dim3(out.stat_nb), dim3(stat_threads(cout)), 0, S.st, (const float *)out.p, out.ld,
+        hipLaunchKernelGGL(k_add_stats, dim3(out.stat_nb), dim3(stat_threads(cout)), 0, S.cur->st, (const float *)out.p, out.ld,
                            (const float *)x.p, x.ld, out.p, out.ld, cout, P, rows_per_block, out.stat);
     }
     return out;
@@ -1049,7 +1061,7 @@ Tensor conv_block(EncState &S, const std::string &p, Tensor x, int cout)
 Tensor avg_pool(EncState &S, const Tensor &x)
 {
     Tensor o = new_tensor(S, x.H / 2, x.W / 2, x.C);
-    hipLaunchKernelGGL(k_avgpool2, dim3(nblk(o.pixels() * (x.C / 4), 256)), dim3(256), 0, S.st, (const float *)x.p, x.ld, x.W, o.p, o.ld,
+    hipLaunchKernelGGL(k_avgpool2, dim3(nblk(o.pixels() * (x.C / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, x.W, o.p, o.ld,
                        x.C, o.H, o.W);
     return o;
 }
@@ -1062,7 +1074,7 @@ Tensor hourglass(EncState &S, const std::string &p, int level, const Tensor &x)
     else low = conv_block(S, p + ".b2_plus_" + std::to_string(level), low, x.C);
     low = conv_block(S, p + ".b3_" + std::to_string(level), low, x.C);
     Tensor out = new_tensor(S, x.H, x.W, x.C);
-    hipLaunchKernelGGL(k_bicubic_up2_add, dim3(nblk(out.pixels() * (x.C / 4), 256)), dim3(256), 0, S.st, (const float *)low.p, low.ld,
+    hipLaunchKernelGGL(k_bicubic_up2_add, dim3(nblk(out.pixels() * (x.C / 4), 256)), dim3(256), 0, S.cur->st, (const float *)low.p, low.ld,
                        low.H, low.W, (const float *)up1.p, up1.ld, out.p, out.ld, x.C);
     return out;
 }
@@ -1078,7 +1090,7 @@ Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_st
     // x = relu(bn1(conv1)) is both normalised again (ConvBlock.bn1/bn4) and used by the shortcut: materialise it
     Affine b1 = norm_affine(S, p + ".bn1", c1, S.norm);
     Tensor x = new_tensor(S, H1, W1, 64);
-    hipLaunchKernelGGL(k_affine_act, dim3(nblk(x.pixels() * 16, 256)), dim3(256), 0, S.st, (const float *)c1.p, c1.ld, b1.scale, b1.shift,
+    hipLaunchKernelGGL(k_affine_act, dim3(nblk(x.pixels() * 16, 256)), dim3(256), 0, S.cur->st, (const float *)c1.p, c1.ld, b1.scale, b1.shift,
                        0.f, x.p, x.ld, 64, x.pixels());
     x = conv_block(S, p + ".conv2", x, 128);
     if (ave_pool) x = avg_pool(S, x);
@@ -1094,7 +1106,7 @@ Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_st
         Affine be = norm_affine(S, p + ".bn_end" + ss, cl, S.norm); be.slope = 0.f;        // relu(bn_end(.)) as a prologue
         const int lc_pad = (int)round_up(last_ch, BK);
         out = new_tensor(S, ll.H, ll.W, lc_pad);                                             // padded so that `al` can read it
-        if (lc_pad != last_ch) (void)hipMemsetAsync(out.p, 0, out.pixels() * lc_pad * sizeof(float), S.st);
+        if (lc_pad != last_ch) (void)hipMemsetAsync(out.p, 0, out.pixels() * lc_pad * sizeof(float), S.cur->st);
         Tensor out_valid = out; out_valid.C = last_ch;
         conv2d(S, p + ".l" + ss + ".weight", p + ".l" + ss + ".bias", cl, be, g1, out_valid);
         if (stacks) stacks->push_back(out_valid);                                            // train mode keeps every stack's output
@@ -1126,7 +1138,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     }
     // the first ResnetBlock consumes relu(IN(x)) as its RAW input and as the residual: materialise it
     Tensor r = new_tensor(S, x.H, x.W, c);
-    hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.st, (const float *)x.p, x.ld, act.scale,
+    hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, act.scale,
                        act.shift, 0.f, r.p, r.ld, c, r.pixels());
     const ConvGeom gr{3, 1, 1, true};
     for (int b = 0; b < 9; ++b) {
@@ -1136,7 +1148,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
         Affine a1 = norm_affine(S, "", h1, inst); a1.slope = 0.f;
         conv2d(S, q + ".5.weight", q + ".5.bias", h1, a1, gr, h2);
         Affine a2 = norm_affine(S, "", h2, inst);
-        hipLaunchKernelGGL(k_add, dim3(nblk(o.pixels() * (c / 4), 256)), dim3(256), 0, S.st, (const float *)r.p, r.ld, (const float *)h2.p,
+        hipLaunchKernelGGL(k_add, dim3(nblk(o.pixels() * (c / 4), 256)), dim3(256), 0, S.cur->st, (const float *)r.p, r.ld, (const float *)h2.p,
                            h2.ld, a2.scale, a2.shift, o.p, o.ld, c, o.pixels());          // x + IN(conv(...))
         r = o; idx += 1;
     }
@@ -1163,7 +1175,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     }
     const float *bias = dev_upload(S, m + ".bias", param(S, m + ".bias").data);
     if (x.C % 16 != 0) throw Fail{"k_conv7_to3_tanh needs a multiple of 16 input channels"};
-    hipLaunchKernelGGL(k_conv7_to3_tanh, dim3((unsigned)(((x.W + 15) / 16) * ((x.H + 15) / 16))), dim3(256), 0, S.st, (const float *)x.p,
+    hipLaunchKernelGGL(k_conv7_to3_tanh, dim3((unsigned)(((x.W + 15) / 16) * ((x.H + 15) / 16))), dim3(256), 0, S.cur->st, (const float *)x.p,
                        x.ld, x.H, x.W, x.C, act.scale, act.shift, (const float *)S.dev[key], bias, dst_nchw);
 }
 
@@ -1171,21 +1183,62 @@ Tensor pack_input(EncState &S, const float *img, int Cimg, int H, int W, const f
 {
     Tensor t = new_tensor(S, H, W, 32);
     if (Cimg + (nF ? 3 : 0) + (nB ? 3 : 0) > 32) throw Fail{"more than 32 input channels"};
-    hipLaunchKernelGGL(k_pack_input, dim3(nblk(t.pixels(), 256)), dim3(256), 0, S.st, img, Cimg, H, W, nF, nB, Hn, Wn, t.p, t.ld);
+    hipLaunchKernelGGL(k_pack_input, dim3(nblk(t.pixels(), 256)), dim3(256), 0, S.cur->st, img, Cimg, H, W, nF, nB, Hn, Wn, t.p, t.ld);
     return t;
 }
 
-int begin(pifu_ctx *ctx, EncState &S, size_t arena_bytes, hipStream_t st)
+// make lane `k` current for a call on the caller's stream `st`: lane 0 issues into `st` itself, lanes 1 and 2 into streams
+// of their own (created on first use); the lane's arena holds at least `arena_bytes` and is empty
+int begin(pifu_ctx *ctx, EncState &S, int k, size_t arena_bytes, hipStream_t st)
 {
     PIFU_HIP(hipSetDevice(ctx->device));
-    int rc = pifu_ensure(S.arena, arena_bytes);
+    Lane &L = S.lanes[k];
+    if (k == 0) L.st = st;
+    else {
+        if (!L.own) PIFU_HIP(hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking));
+        L.st = L.own;
+    }
+    if (!S.ev_fork) {
+        PIFU_HIP(hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
+        PIFU_HIP(hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming));
+        PIFU_HIP(hipEventCreateWithFlags(&S.ev_coarse, hipEventDisableTiming));
+    }
+    int rc = pifu_ensure(L.arena, arena_bytes);
     if (rc) return rc;
-    S.used = 0;
-    S.st = st;
+    L.used = 0;
+    S.cur = &L;
+    return PIFU_OK;
+}
+
+// lane `k` continues from what `from` has issued so far
+int fork_lane(EncState &S, int k, hipStream_t from)
+{
+    PIFU_HIP(hipEventRecord(S.ev_fork, from));
+    PIFU_HIP(hipStreamWaitEvent(S.lanes[k].st, S.ev_fork, 0));
+    return PIFU_OK;
+}
+
+// `to` continues only after everything lane `k` has issued so far
+int join_lane(EncState &S, int k, hipStream_t to)
+{
+    PIFU_HIP(hipEventRecord(S.ev_join, S.lanes[k].st));
+    PIFU_HIP(hipStreamWaitEvent(to, S.ev_join, 0));
     return PIFU_OK;
 }
 
 }  // namespace
+
+// A coarse call issued with PIFU_ENC_DEFER_JOIN leaves its hourglass running on a stream of the library; whoever reads the
+// coarse feature map next - every query / grid entry point, pifu_set_features, the next filter call - first makes its own
+// stream wait for it here.
+int pifu_enc_join(pifu_ctx *ctx, hipStream_t st)
+{
+    auto it = g_states.find(ctx);
+    if (it == g_states.end() || !it->second->coarse_pending) return PIFU_OK;
+    PIFU_HIP(hipStreamWaitEvent(st, it->second->ev_coarse, 0));
+    it->second->coarse_pending = false;
+    return PIFU_OK;
+}
 
 extern "C" int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host, const int64_t *shape, int rank)
 {
@@ -1222,9 +1275,14 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &kv : it->second->dev) (void)hipFree(kv.second);
-    if (it->second->arena.p) (void)hipFree(it->second->arena.p);
-    if (it->second->splitk.p) (void)hipFree(it->second->splitk.p);
-    if (it->second->prep.p) (void)hipFree(it->second->prep.p);
+    for (Lane &L : it->second->lanes) {
+        if (L.arena.p) (void)hipFree(L.arena.p);
+        if (L.splitk.p) (void)hipFree(L.splitk.p);
+        if (L.prep.p) (void)hipFree(L.prep.p);
+        if (L.own) (void)hipStreamDestroy(L.own);
+    }
+    for (hipEvent_t e : {it->second->ev_fork, it->second->ev_join, it->second->ev_coarse})
+        if (e) (void)hipEventDestroy(e);
     delete it->second;
     g_states.erase(it);
     return PIFU_OK;
@@ -1233,24 +1291,50 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
 // PIFuNetwNML.filter (PIFuNetwNML.py:73-97)
 extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                                   int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
-                                  float *feat_nchw, int all_stacks, pifu_stream stream)
+                                  float *feat_nchw, int flags, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && img_nchw, PIFU_ERR_INVALID, "pifu_filter_coarse: null argument");
     PIFU_REQUIRE(H % 16 == 0 && W % 16 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_coarse: H, W must be multiples of 16");
     PIFU_REQUIRE((!use_front || nmlF) && (!use_back || nmlB), PIFU_ERR_INVALID, "pifu_filter_coarse: normal-map output buffers missing");
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_coarse: bad norm / hg_dim");
+    const bool all_stacks = (flags & PIFU_ENC_ALL_STACKS) != 0, defer = (flags & PIFU_ENC_DEFER_JOIN) != 0;
     EncState &S = state_of(ctx);
+    hipStream_t st = (hipStream_t)stream;
     const size_t px = (size_t)H * W;
-    int rc = begin(ctx, S, px * 4 * (size_t)(2600 + 700 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
+    int rc = pifu_enc_join(ctx, st);      // an earlier deferred hourglass still owns the map this call replaces
     if (rc) return rc;
     try {
+        // the two normal nets read the same packed image and nothing of each other: netF on the caller's stream (lane 0),
+        // netB beside it on lane 1
         if (use_front || use_back) {
+            rc = begin(ctx, S, 0, px * 4 * (size_t)1000 + ((size_t)320 << 20), st);
+            if (rc) return rc;
             Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W);
             S.fuse_stats = true;          // every conv of the normal nets is followed by an InstanceNorm
-            if (use_front) { const size_t mark = S.used; global_generator(S, "netF", in, nmlF); S.used = mark; }
-            if (use_back) { const size_t mark = S.used; global_generator(S, "netB", in, nmlB); S.used = mark; }
-            S.used = 0;   // stream order keeps the reuse safe
+            const bool side = use_front && use_back;
+            if (side) {         // lane 1 starts from the packed image, BEFORE anything of netF is in the caller's stream
+                rc = begin(ctx, S, 1, px * 4 * (size_t)1000 + ((size_t)320 << 20), st);
+                if (rc) return rc;
+                rc = fork_lane(S, 1, st);
+                if (rc) return rc;
+                global_generator(S, "netB", in, nmlB);
+                S.cur = &S.lanes[0];
+                global_generator(S, "netF", in, nmlF);
+                rc = join_lane(S, 1, st);
+                if (rc) return rc;
+            } else if (use_front) {
+                global_generator(S, "netF", in, nmlF);
+            } else {
+                global_generator(S, "netB", in, nmlB);
+            }
         }
+        // the hourglass filter runs on lane 2: with PIFU_ENC_DEFER_JOIN the call returns while it is still running - the fine
+        // level (pifu_filter_fine, lane 0) does not read its result and fills the chip beside it - otherwise the caller's
+        // stream waits for it before the call returns
+        rc = begin(ctx, S, 2, px * 4 * (size_t)(1600 + 700 * num_stack) + ((size_t)320 << 20), st);
+        if (rc) return rc;
+        rc = fork_lane(S, 2, st);
+        if (rc) return rc;
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W);
         S.norm = norm;
         S.fuse_stats = norm != 0;         // eval-mode BatchNorm needs no statistics
@@ -1267,15 +1351,23 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         }
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
-                                  hipMemcpyDeviceToDevice, S.st));
+                                  hipMemcpyDeviceToDevice, S.cur->st));
         if (feat_nchw && all_stacks) {      // train mode (PIFuNetwNML.py:94-97 keeps the whole list): [num_stack][C][H/4][W/4]
             for (size_t k = 0; k < stacks.size(); ++k)
-                hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)stacks[k].p,
+                hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.cur->st, (const float *)stacks[k].p,
                                    stacks[k].ld, f.C, (int)f.pixels(), feat_nchw + k * f.pixels() * f.C);
         } else if (feat_nchw)
-            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)f.p, f.ld, f.C,
+            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.cur->st, (const float *)f.p, f.ld, f.C,
                                (int)f.pixels(), feat_nchw);
+        PIFU_HIP(hipEventRecord(S.ev_coarse, S.cur->st));
+        S.coarse_pending = true;
+        S.cur = &S.lanes[0];
+        if (!defer) {
+            rc = pifu_enc_join(ctx, st);
+            if (rc) return rc;
+        }
     } catch (const Fail &e) {
+        S.cur = &S.lanes[0];
         pifu_set_error("pifu_filter_coarse: %s", e.msg.c_str());
         return PIFU_ERR_STATE;
     }
@@ -1293,7 +1385,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_fine: bad norm / hg_dim");
     EncState &S = state_of(ctx);
     const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
-    int rc = begin(ctx, S, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
+    int rc = begin(ctx, S, 0, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
     if (rc) return rc;
     try {
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
@@ -1310,14 +1402,15 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
         }
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
-                                  hipMemcpyDeviceToDevice, S.st));
+                                  hipMemcpyDeviceToDevice, S.cur->st));
         if (feat_nchw)
-            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.st, (const float *)f.p, f.ld, f.C,
+            hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.cur->st, (const float *)f.p, f.ld, f.C,
                                (int)f.pixels(), feat_nchw);
     } catch (const Fail &e) {
         pifu_set_error("pifu_filter_fine: %s", e.msg.c_str());
         return PIFU_ERR_STATE;
     }
     PIFU_HIP(hipGetLastError());
-    return PIFU_OK;
+    // a coarse hourglass the previous call left running beside this one: both levels are complete for whatever comes next
+    return pifu_enc_join(ctx, (hipStream_t)stream);
 }

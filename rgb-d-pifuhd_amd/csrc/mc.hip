@@ -35,7 +35,17 @@ __device__ __constant__ const signed char TI[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5},
                                                       {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0}, {0, 4, 3, 7, 2, 6, 1, 5},
                                                       {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
 
-__device__ bool test_face(const double *c, int f)
+// the 8 values (v - level) of the cell being classified.  The ambiguity tests index them by table entries, i.e. dynamically:
+// held in registers that costs a scratch array per lane (measured: 64 B written and re-read per cell of every active
+// brick, 340 MB per 512^3 call); they live in LDS instead, corner i of thread t at [i * 256 + t] (conflict-free), as the
+// float32 samples (8 KB per block: the counting pass is latency-bound and lives on its occupancy)
+struct Corners {
+    const float *p;            // the float32 samples; v - level is formed in double on every read, as classify() forms it
+    double level;
+    __device__ __forceinline__ double operator[](int i) const { return (double)p[i * 256] - level; }
+};
+
+__device__ bool test_face(const Corners c, int f)
 {
     int A, B, C, D;
     switch (f < 0 ? -f : f) {
@@ -51,7 +61,7 @@ __device__ bool test_face(const double *c, int f)
     return __dmul_rn(__dmul_rn((double)f, c[A]), d) >= 0;
 }
 
-__device__ bool test_interior(const double *c, int mc_case, int cfg, int subcfg, int s)
+__device__ bool test_interior(const Corners c, int mc_case, int cfg, int subcfg, int s)
 {
     double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
     if (mc_case == 4 || mc_case == 10) {
@@ -97,7 +107,7 @@ __device__ bool test_interior(const double *c, int mc_case, int cfg, int subcfg,
 }
 
 // triangle row of a cell; returns the number of triangles
-__device__ int choose_tiling(const double *c, int index, const signed char **row)
+__device__ int choose_tiling(const Corners c, int index, const signed char **row)
 {
     const int mc_case = MC_CASES[index][0], cfg = MC_CASES[index][1];
     int sc, s13, k;
@@ -188,42 +198,45 @@ struct Vol {
     int zoff;
 };
 
-__device__ __forceinline__ double vol_at(const Vol &v, int z, int y, int x)
+__device__ __forceinline__ float vol_f32(const Vol &v, int z, int y, int x)
 {
     const size_t i = ((size_t)z * v.n1 + y) * v.n2 + x;
-    return v.dtype == 0 ? (double)((const float *)v.p)[i] : (double)(float)((const double *)v.p)[i];
+    return v.dtype == 0 ? ((const float *)v.p)[i] : (float)((const double *)v.p)[i];
 }
+
+__device__ __forceinline__ double vol_at(const Vol &v, int z, int y, int x) { return (double)vol_f32(v, z, y, x); }
 
 struct CellInfo {
     const signed char *row;
     int nt;
     int nown;                  // vertices this cell creates
     uint64_t own;              // their edge ids (12 = the centre vertex), 4 bits each, in the order the cell numbers them
-    int x, y, z;
-    double c[8];
 };
 
-// classify one cell; fills c[], row, nt and the owned vertices.  Returns false for an empty cell.
-__device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci)
+// classify one cell (blocks of 256 threads; `corners`: 8 x 256 doubles of LDS); fills row, nt and the owned vertices.
+// Returns false for an empty cell.
+__device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci, float *corners)
 {
-    ci.x = (int)(cell % v.c2);
-    ci.y = (int)((cell / v.c2) % v.c1);
-    ci.z = (int)(cell / ((int64_t)v.c2 * v.c1));
+    const int x = (int)(cell % v.c2), y = (int)((cell / v.c2) % v.c1), z = (int)(cell / ((int64_t)v.c2 * v.c1));
     ci.nt = 0;
     ci.nown = 0;
     ci.own = 0;
     ci.row = nullptr;
     // a cell of a brick whose nodes all lie on one side of the level has index 0 or 255: nothing to load
-    if (v.brick && !v.brick[((size_t)(ci.z >> 3) * v.b1 + (ci.y >> 3)) * v.b2 + (ci.x >> 3)]) return false;
+    if (v.brick && !v.brick[((size_t)(z >> 3) * v.b1 + (y >> 3)) * v.b2 + (x >> 3)]) return false;
     int index = 0;
+    float d[8];                                                  // constant indices only: registers
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        ci.c[i] = vol_at(v, ci.z + COFF[i][2], ci.y + COFF[i][1], ci.x + COFF[i][0]) - v.level;
-        if (ci.c[i] > 0) index |= 1 << i;
+        d[i] = vol_f32(v, z + COFF[i][2], y + COFF[i][1], x + COFF[i][0]);
+        if (((double)d[i] - v.level) > 0) index |= 1 << i;
     }
     if (index == 0 || index == 255) return false;
-    ci.nt = choose_tiling(ci.c, index, &ci.row);
-    const int zero_mask = (ci.x == 0 ? 1 : 0) | (ci.y == 0 ? 2 : 0) | (ci.z + v.zoff == 0 ? 4 : 0);
+    float *mine = corners + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[i * 256] = d[i];
+    ci.nt = choose_tiling(Corners{mine, v.level}, index, &ci.row);
+    const int zero_mask = (x == 0 ? 1 : 0) | (y == 0 ? 2 : 0) | (z + v.zoff == 0 ? 4 : 0);
     unsigned seen = 0;
     for (int k = 0; k < 3 * ci.nt; ++k) {
         const int e = ci.row[k];
@@ -250,13 +263,16 @@ __device__ __forceinline__ unsigned regions_of(unsigned Z)
     return (unsigned)((0xff553311'0f050301ull >> (8 * Z)) & 0xffu);
 }
 
+// VEC = 2: a thread takes two consecutive x per row with one 16-byte (float64) / 8-byte (float32) load - needs an even n2;
+// VEC = 1: one x per thread and row, any n2
+template <int VEC>
 __global__ __launch_bounds__(256) void k_mc_nodebricks(const Vol v, int nb1, int nb2, uint16_t *nbflags, float *mm /* [2*gridDim] */)
 {
     __shared__ float smin[4], smax[4];
     const int by = blockIdx.x % nb1, bz = blockIdx.x / nb1;
     float lo = INFINITY, hi = -INFINITY;
-    for (int x0 = 0; x0 < nb2 * 8; x0 += 256) {
-        const int x = x0 + threadIdx.x;
+    for (int x0 = 0; x0 < nb2 * 8; x0 += 256 * VEC) {
+        const int x = x0 + (int)threadIdx.x * VEC;
         unsigned pos = 0, neg = 0;
         if (x < v.n2) {
             const unsigned zx = (x & 7) == 0 ? 1u : 0u;
@@ -268,19 +284,32 @@ __global__ __launch_bounds__(256) void k_mc_nodebricks(const Vol v, int nb1, int
                     const int y = by * 8 + dy;
                     if (y >= v.n1) break;                                    // block-uniform
                     const size_t i = ((size_t)z * v.n1 + y) * v.n2 + x;
-                    const float f = v.dtype == 0 ? ((const float *)v.p)[i] : (float)((const double *)v.p)[i];
-                    lo = fminf(lo, f);
-                    hi = fmaxf(hi, f);
-                    const unsigned reg = regions_of(zx | (dy == 0 ? 2u : 0u) | (dz == 0 ? 4u : 0u));
-                    if (((double)f - v.level) > 0) pos |= reg; else neg |= reg;
+                    float f[VEC];
+                    if (VEC == 1) {
+                        f[0] = v.dtype == 0 ? ((const float *)v.p)[i] : (float)((const double *)v.p)[i];
+                    } else if (v.dtype == 0) {
+                        const float2 t = *reinterpret_cast<const float2 *>((const float *)v.p + i);
+                        f[0] = t.x; f[VEC - 1] = t.y;
+                    } else {
+                        const double2 t = *reinterpret_cast<const double2 *>((const double *)v.p + i);
+                        f[0] = (float)t.x; f[VEC - 1] = (float)t.y;
+                    }
+                    const unsigned zyz = (dy == 0 ? 2u : 0u) | (dz == 0 ? 4u : 0u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        lo = fminf(lo, f[k]);
+                        hi = fmaxf(hi, f[k]);
+                        const unsigned reg = regions_of((k == 0 ? zx : 0u) | zyz);
+                        if (((double)f[k] - v.level) > 0) pos |= reg; else neg |= reg;
+                    }
                 }
             }
         }
         unsigned both = pos | (neg << 8);
         both |= __shfl_xor(both, 1);
         both |= __shfl_xor(both, 2);
-        both |= __shfl_xor(both, 4);
-        if ((threadIdx.x & 7) == 0 && (x >> 3) < nb2) nbflags[((size_t)bz * nb1 + by) * nb2 + (x >> 3)] = (uint16_t)both;
+        if (VEC == 1) both |= __shfl_xor(both, 4);
+        if ((threadIdx.x & (8 / VEC - 1)) == 0 && (x >> 3) < nb2) nbflags[((size_t)bz * nb1 + by) * nb2 + (x >> 3)] = (uint16_t)both;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -295,16 +324,22 @@ __global__ __launch_bounds__(256) void k_mc_nodebricks(const Vol v, int nb1, int
     }
 }
 
-__global__ void k_mc_minmax_final(const float *part, int n, float *out)
+__global__ __launch_bounds__(256) void k_mc_minmax_final(const float *part, int n, float *out)
 {
+    __shared__ float smin[4], smax[4];
     float lo = INFINITY, hi = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 64) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+    for (int i = threadIdx.x; i < n; i += 256) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if (threadIdx.x == 0) { out[0] = lo; out[1] = hi; }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        out[1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
 }
 
 __global__ void k_mc_brick_combine(const Vol v, int nb0, int nb1, int nb2, const uint16_t *nbflags, uint8_t *brick)
@@ -325,7 +360,7 @@ __global__ void k_mc_brick_combine(const Vol v, int nb0, int nb1, int nb2, const
     brick[b] = (pos && neg) ? 1 : 0;
 }
 
-constexpr int MC_GPB = 16;      // groups of 256 cells per block of the counting pass
+constexpr int MC_GPB = 32;      // groups of 256 cells per block of the counting pass
 
 // which groups of 256 consecutive cells can hold a surface cell at all: one thread per group walks its cells brick by brick
 __global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)
@@ -358,12 +393,40 @@ struct SurfList {
 };
 
 // pass 1: group g covers cells [256 g, 256 g + 256) of the serial scan; per group (vertices << 32 | triangles) created,
-// and the records of its surface cells
-__global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const SurfList L, unsigned long long *nsurf)
+// and the records of its surface cells.  A block gathers the records of its MC_GPB groups in LDS and takes its place in the
+// list with ONE atomic (a device-wide counter is a fabric round trip per access: one per group made this pass 2x slower
+// than the classification itself), then copies them out with consecutive lanes on consecutive records.
+constexpr int MC_REC_CAP = 256;       // records buffered per block (7 KB); a fuller buffer is flushed before the next group
+
+__global__ __launch_bounds__(256) void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const SurfList L, unsigned long long *nsurf)
 {
     __shared__ uint32_t sh[4];
     __shared__ uint32_t wcnt[4];
     __shared__ unsigned long long base_sh;
+    __shared__ float corners[8 * 256];
+    __shared__ int64_t r_cell[MC_REC_CAP];
+    __shared__ const signed char *r_row[MC_REC_CAP];
+    __shared__ uint64_t r_own[MC_REC_CAP];
+    __shared__ uint32_t r_meta[MC_REC_CAP];
+    uint32_t nbuf = 0;                                           // block-uniform: every thread keeps the same count
+
+    auto flush = [&]() {
+        if (threadIdx.x == 0) base_sh = atomicAdd(nsurf, (unsigned long long)nbuf);
+        __syncthreads();                                         // also: every record of the batch is in LDS
+        const int64_t base = (int64_t)base_sh;
+        for (uint32_t i = threadIdx.x; i < nbuf; i += 256) {
+            const int64_t slot = base + i;
+            if (slot < L.cap) {                                  // past the capacity: counted only, the host grows the list and reruns
+                L.cell[slot] = r_cell[i];
+                L.row[slot] = r_row[i];
+                L.own[slot] = r_own[i];
+                L.meta[slot] = r_meta[i];
+            }
+        }
+        __syncthreads();                                         // the buffer may be refilled
+        nbuf = 0;
+    };
+
     for (int gi = 0; gi < MC_GPB; ++gi) {
         const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
         if (group >= ngroups) break;
@@ -374,7 +437,7 @@ __global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const
         const int64_t cell = group * 256 + threadIdx.x;
         CellInfo ci;
         bool active = false;
-        if (cell < v.ncells) active = classify(v, cell, ci);
+        if (cell < v.ncells) active = classify(v, cell, ci, corners);
         const uint32_t packed = active ? ((uint32_t)ci.nown | ((uint32_t)ci.nt << 16)) : 0u;
         uint32_t tot;
         const uint32_t pre = block_exclusive_scan_256(packed, sh, &tot);
@@ -389,21 +452,18 @@ __global__ void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const
             if (w < wave) spre += wcnt[w];
             stot += wcnt[w];
         }
-        if (threadIdx.x == 0) {
-            blk_vt[group] = ((uint64_t)(tot & 0xffffu) << 32) | (uint64_t)(tot >> 16);
-            base_sh = stot ? atomicAdd(nsurf, (unsigned long long)stot) : 0ull;
-        }
-        __syncthreads();
+        if (threadIdx.x == 0) blk_vt[group] = ((uint64_t)(tot & 0xffffu) << 32) | (uint64_t)(tot >> 16);
+        if (nbuf + stot > MC_REC_CAP) flush();                   // block-uniform (stot <= 256 always fits an empty buffer)
         if (active) {
-            const int64_t slot = (int64_t)base_sh + spre;
-            if (slot < L.cap) {                                  // past the capacity: counted only, the host grows the list and reruns
-                L.cell[slot] = cell;
-                L.row[slot] = ci.row;
-                L.own[slot] = ci.own;
-                L.meta[slot] = (pre & 0xfffu) | (((pre >> 16) & 0xfffu) << 12) | ((uint32_t)ci.nown << 24) | ((uint32_t)ci.nt << 28);
-            }
+            const uint32_t i = nbuf + spre;
+            r_cell[i] = cell;
+            r_row[i] = ci.row;
+            r_own[i] = ci.own;
+            r_meta[i] = (pre & 0xfffu) | (((pre >> 16) & 0xfffu) << 12) | ((uint32_t)ci.nown << 24) | ((uint32_t)ci.nt << 28);
         }
+        nbuf += stot;
     }
+    if (nbuf) flush();                                           // block-uniform
 }
 
 __device__ __forceinline__ size_t edge_slot(const Vol &v, int axis, int z, int y, int x)
@@ -569,8 +629,11 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
         a = carve(v, (char *)ctx->mc_arena.p, cap);
         const int npencils = a.nb0 * a.nb1;
         v.brick = nullptr; v.gflag = nullptr;
-        hipLaunchKernelGGL(k_mc_nodebricks, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
-        hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(64), 0, st, (const float *)(a.mm + 2), npencils, a.mm);
+        // two x per thread when the rows (and with them every 16-byte load) are aligned
+        const bool vec = n2 % 2 == 0 && ((uintptr_t)volume % 16) == 0;
+        if (vec) hipLaunchKernelGGL(k_mc_nodebricks<2>, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
+        else hipLaunchKernelGGL(k_mc_nodebricks<1>, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
+        hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(256), 0, st, (const float *)(a.mm + 2), npencils, a.mm);
         hipLaunchKernelGGL(k_mc_brick_combine, dim3((unsigned)((a.nbricks + 255) / 256)), dim3(256), 0, st, v, a.nb0, a.nb1, a.nb2,
                            (const uint16_t *)a.nbflags, a.brick);
         v.brick = a.brick;

@@ -156,6 +156,8 @@ int pifu_prof_begin(pifu_ctx *ctx, int slot, hipStream_t st, hipEvent_t *stop);
 int pifu_prof_end(pifu_ctx *ctx, int slot, hipEvent_t stop, double work, hipStream_t st);
 
 int pifu_ensure(DevBuf &b, size_t bytes);   // grow-only hipMalloc (synchronises when it grows)
+// encoder.hip: make `st` wait for a coarse hourglass that pifu_filter_coarse(PIFU_ENC_DEFER_JOIN) left running
+int pifu_enc_join(pifu_ctx *ctx, hipStream_t st);
 
 // implemented in query.hip
 int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n, const int32_t *res,

@@ -1165,6 +1165,10 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
     PIFU_REQUIRE(C > 0 && C % 4 == 0 && H > 1 && W > 1, PIFU_ERR_INVALID,
                  "pifu_set_features: need C %% 4 == 0 and H, W > 1 (got C=%d H=%d W=%d)", C, H, W);
     PIFU_HIP(hipSetDevice(ctx->device));
+    {
+        const int rc = pifu_enc_join(ctx, (hipStream_t)stream);      // a deferred coarse hourglass may still be writing its map
+        if (rc) return rc;
+    }
     FeatMap &f = ctx->feat[level];
     const size_t bytes = (size_t)H * W * C * sizeof(float);
     if (bytes > f.bytes) {
@@ -1618,6 +1622,10 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "null context");
     PIFU_REQUIRE(n >= 0 && chunk > 0, PIFU_ERR_INVALID, "query: need n >= 0 and chunk > 0");
     if (n == 0) return PIFU_OK;
+    {
+        const int rc = pifu_enc_join(ctx, st);      // a coarse hourglass left running by pifu_filter_coarse(PIFU_ENC_DEFER_JOIN)
+        if (rc) return rc;
+    }
     const bool coarse_only = flags & PIFU_Q_COARSE_ONLY;
     const bool fine = !coarse_only;
     PIFU_REQUIRE(ctx->mlp[0].defined && ctx->feat[0].nhwc, PIFU_ERR_STATE,

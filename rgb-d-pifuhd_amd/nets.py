@@ -270,8 +270,10 @@ class PIFuNetwNML(BasePIFuNet):
         return self
 
     # -- filter ------------------------------------------------------------------------------------
-    def filter(self, images):
-        """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`)."""
+    def filter(self, images, _defer=False):
+        """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`).  `_defer=True` (used by `reconstruction._Subject`, which calls
+        `filter_local` next): return while the hourglass is still running on a stream of the library, so that the fine
+        level runs beside it; `im_feat_list` must then not be read before `filter_local` / a query has been issued."""
         self._sync_weights()
         images = images.to(self.device, torch.float32).contiguous()
         if images.dim() != 4 or images.shape[0] != 1:
@@ -291,7 +293,8 @@ class PIFuNetwNML(BasePIFuNet):
         feat = torch.empty(stacks, o.hg_dim, h // 4, w // 4, device=self.device)
         _lib.call('pifu_filter_coarse', self._ctx.h, _ptr(images), cimg, h, w, int(o.num_stack), int(o.hg_depth),
                   int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1, int(use_f), int(use_b), _ptr(self.nmlF),
-                  _ptr(self.nmlB), _ptr(feat), int(self.training), _stream_ptr(self.device))
+                  _ptr(self.nmlB), _ptr(feat), (_lib.ENC_ALL_STACKS if self.training else 0) | (_lib.ENC_DEFER_JOIN if _defer else 0),
+                  _stream_ptr(self.device))
         self.im_feat_list = [feat[k:k + 1] for k in range(stacks)]
         self.normx = None                   # never read on the reconstruction path
 
@@ -421,9 +424,9 @@ class PIFuMRNet(BasePIFuNet):
             self._push_weights()
 
     # -- filter ------------------------------------------------------------------------------------
-    def filter_global(self, images):
-        """`PIFuMRNet.filter_global` (`PIFuMRNet.py:71-81`)."""
-        self.netG.filter(images)
+    def filter_global(self, images, _defer=False):
+        """`PIFuMRNet.filter_global` (`PIFuMRNet.py:71-81`); `_defer`: see `PIFuNetwNML.filter`."""
+        self.netG.filter(images, _defer=_defer)
 
     def filter_local(self, images, rect=None):
         """`PIFuMRNet.filter_local` (`PIFuMRNet.py:83-118`): images [1,1,C,H,W]."""

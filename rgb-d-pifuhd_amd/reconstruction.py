@@ -53,6 +53,26 @@ def _normal_spans(n_verts, interval=50000):
     return spans
 
 
+_copy_streams = {}
+
+
+def _upload_beside(t, dev):
+    """`t.to(dev)` issued on a copy stream of its own, so that the transfer does not queue behind the kernels already
+    issued on the current stream; the current stream waits for it."""
+    dev = torch.device(dev)
+    if t.device == dev:
+        return t
+    side = _copy_streams.get(dev)
+    if side is None:
+        side = _copy_streams[dev] = torch.cuda.Stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        out = t.to(device=dev, non_blocking=True)
+    cur.wait_stream(side)
+    out.record_stream(cur)
+    return out
+
+
 class _Subject:
     """One subject on the device after both encoders ran: what every `gen_mesh*` variant of the reference starts with
     (`reconstruction.py:29-45` and its two copies at `:81-97`, `:131-147`)."""
@@ -60,9 +80,12 @@ class _Subject:
     def __init__(self, net, data):
         dev = net.device
         self.calib = data['calib'].to(device=dev)
-        self.image_fine = data['img'].to(device=dev)
         coarse = data['img_512'].to(device=dev)
-        net.filter_global(coarse)
+        # same two calls as the reference, arranged so that independent work overlaps: the coarse call returns while its
+        # hourglass still runs (the fine level does not read it), and the 1024 px image crosses PCIe on a copy stream while
+        # the normal nets compute
+        net.filter_global(coarse, _defer=True)
+        self.image_fine = _upload_beside(data['img'], dev)
         net.filter_local(self.image_fine[:, None])
         # the strip saved beside the mesh: input | front normal | back normal, as far as the coarse net predicts them; of an
         # RGB-D input (6 channels, SURVEY C-7) the colour half is shown

@@ -187,3 +187,36 @@ def test_full_size_encoders_to_occupancy_end_to_end(golden_dir):
     # is not vanishing (the reference divides by |g| + 1e-8)
     cos = (got_n * want_n).sum(0)
     assert np.median(cos) > 0.999 and (cos > 0.9).mean() > 0.97
+
+
+def test_overlapped_encoder_schedule_is_bit_identical():
+    """`reconstruction._Subject` issues the two filter calls so that independent work overlaps (netF beside netB inside the
+    coarse call, the coarse hourglass - left running by PIFU_ENC_DEFER_JOIN - beside the fine level, the fine image's upload
+    beside the normal nets).  Only the schedule changes: every output must be bit-identical to the plain
+    `filter_global(); filter_local()` sequence, call after call, and a query issued right after must see both maps."""
+    from pifuhd_amd import config, nets, reconstruction, synth
+    from helpers import seeded_points
+    oc = config.coarse_opt(); of = config.fine_opt(oc)
+    of.loadSizeBig = 256
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = {'name': 't', 'img': synth.synthetic_image(256, 3, seed=3), 'img_512': synth.synthetic_image(128, 3, seed=2),
+            'calib': synth.synthetic_inputs(512, 3)['calib'], 'b_min': [-1, -1, -1], 'b_max': [1, 1, 1]}
+    pts = seeded_points(5, 3000)
+    calib = data['calib']
+    netMR.filter_global(data['img_512'])
+    netMR.filter_local(data['img'][:, None])
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (netG.nmlF, netG.nmlB, netG.im_feat_list[0], netMR.im_feat_list[0])]
+    netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)
+    want_pred = netMR.get_preds().clone()
+    for _ in range(3):
+        reconstruction._Subject(netMR, data)
+        netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)      # joins the deferred hourglass itself
+        assert torch.equal(netMR.get_preds(), want_pred)
+        got = [netG.nmlF, netG.nmlB, netG.im_feat_list[0], netMR.im_feat_list[0]]
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+    # a deferred coarse call followed directly by a coarse-only query (no filter_local in between)
+    netG.filter(data['img_512'], _defer=True)
+    netG.query(pts, calib)
+    assert torch.equal(netG.im_feat_list[0], want[2])

@@ -299,9 +299,11 @@ def test_meshcleaning_and_recolouring_on_analytic_bodies(tmp_path):
 def test_meshcleaning_merges_coincident_vertices_like_the_trimesh_loader(tmp_path):
     """`trimesh.load` merges vertices that share a position before `split()` runs, and the OBJ carries 4 decimals: the
     marching-cubes vertices around a grid node whose value all but equals the level coincide after the round trip.  The
-    merge leaves degenerate triangles behind (kept: validate=False), so the body that owns them is no longer watertight
-    and `split()` drops it.  Here that happens to the WIDE ellipsoid: the taller, narrower one must be kept - by the
-    product exactly as by the restated pipeline of the oracle."""
+    merge turns the sliver triangles between them into degenerate ones (kept: validate=False); each has an edge no other
+    face uses, so it is a non-watertight component of its own and `split()` drops it, while the body around it closes up
+    over the merged vertex (its faces on either side of a sliver now share an edge) and stays watertight.  The product
+    must do exactly what the restated pipeline of the oracle does: same kept vertices (fewer than the file holds, in file
+    order), same faces."""
     from oracle import pifu_oracle as O
     from pifuhd_amd import mesh_util, reconstruction
     from pifuhd_amd.nets import _Ctx
@@ -311,10 +313,14 @@ def test_meshcleaning_merges_coincident_vertices_like_the_trimesh_loader(tmp_pat
     wide = 1 - np.sqrt(((X + 0.1) / 0.55) ** 2 + ((Y - 0.45) / 0.2) ** 2 + (Z / 0.3) ** 2)
     tall = 1 - np.sqrt(((X - 0.3) / 0.2) ** 2 + ((Y + 0.35) / 0.4) ** 2 + (Z / 0.25) ** 2)
     vol = (0.5 + 0.5 * np.maximum(wide, tall)).astype(np.float32)
-    # a node of the wide body's surface shell gets a value a hair above the level: every crossing on its edges lands within
-    # 1e-6 of the node, and 4 decimals cannot tell them apart
-    shell = np.argwhere((np.abs(vol - 0.5) < 0.02) & (Y > 0.2))
-    node = tuple(shell[len(shell) // 2])
+    # an inside node of the wide body with two or more outside neighbours gets a value a hair above the level: the crossings
+    # on its edges land within 1e-5 cells of it.  Even indices: the node's coordinates (multiples of 1/16) are exact at 4
+    # decimals, so the crossings round onto the node from either side (odd nodes sit on rounding ties)
+    inside = vol > 0.5
+    outside_nb = sum((~np.roll(inside, sh, axis=ax)).astype(int) for ax in range(3) for sh in (1, -1))
+    I, J, K = np.indices(vol.shape)
+    cand = np.argwhere(inside & (outside_nb >= 2) & (Y > 0.2) & (I % 2 == 0) & (J % 2 == 0) & (K % 2 == 0))
+    node = tuple(cand[len(cand) // 2])
     vol[node] = np.float32(0.5 + 2e-7)
     v, f = mesh_util.marching_cubes_device(_Ctx('cuda'), torch.from_numpy(vol).cuda(), 0.5)
     verts = v.cpu().numpy().astype(np.float64) * (2.0 / R) - 1.0
@@ -328,15 +334,18 @@ def test_meshcleaning_merges_coincident_vertices_like_the_trimesh_loader(tmp_pat
     ov, oc_, of_ = O.merge_vertices(v0, c0, f0)
     assert np.array_equal(mv, ov) and np.array_equal(mc, oc_) and np.array_equal(mf, of_)
     assert len(mv) < len(v0) and len(mf) == len(f0)                               # merged; no face dropped
-    assert ((mf[:, 0] == mf[:, 1]) | (mf[:, 1] == mf[:, 2]) | (mf[:, 0] == mf[:, 2])).any()      # degenerate ones stay
+    degenerate = (mf[:, 0] == mf[:, 1]) | (mf[:, 1] == mf[:, 2]) | (mf[:, 0] == mf[:, 2])
+    assert degenerate.any()                                                       # the slivers stay in the face list
+    # the component test itself against the serial restatement, on the merged mesh
+    keep = reconstruction.largest_component(mv, mf, 'cuda')
+    assert np.array_equal(keep, O.widest_watertight_component(mv, mf))
+    assert not degenerate[keep].any()                                             # ... but in no watertight component
     want = _plus_oracle(base, calib_tensor())
     assert not isinstance(want, Exception)
     kept_v, kept_rgba, kept_f = reconstruction.meshcleaning(base, 'cuda')
     assert np.array_equal(kept_v, want[0]) and np.array_equal(kept_f, want[1])
-    assert kept_v[:, 1].max() < 0.2 and np.ptp(kept_v[:, 0]) < 0.5                # the tall body: the wide one stopped being watertight
-    # the component test itself against the serial restatement, on the merged mesh
-    keep = reconstruction.largest_component(mv, mf, 'cuda')
-    assert np.array_equal(keep, O.widest_watertight_component(mv, mf))
+    assert kept_v[:, 1].min() > 0.2 and np.ptp(kept_v[:, 0]) > 1.0                # still the wide body, closed over the merged vertex
+    assert len(np.unique(kept_v, axis=0)) == len(kept_v)
 
 
 def test_gen_mesh_imgcolor_plus(tmp_path, capsys):
