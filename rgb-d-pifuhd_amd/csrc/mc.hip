@@ -360,7 +360,7 @@ __global__ void k_mc_brick_combine(const Vol v, int nb0, int nb1, int nb2, const
     brick[b] = (pos && neg) ? 1 : 0;
 }
 
-constexpr int MC_GPB = 32;      // groups of 256 cells per block of the counting pass
+constexpr int MC_GPB = 4;       // groups of 256 cells per block of the counting pass
 
 // which groups of 256 consecutive cells can hold a surface cell at all: one thread per group walks its cells brick by brick
 __global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)

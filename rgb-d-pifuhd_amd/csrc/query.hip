@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 #include "gemm_predecessors.inc"
 #include "gemm_dma.inc"
 #include "gemm_wide32.inc"
+#include "gemm_adma.inc"
 #ifdef PIFU_GEMM_EXPERIMENTS
 #include "gemm_experiments.inc"
 #endif
