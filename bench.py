@@ -641,7 +641,12 @@ def main():
                         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(ach / PEAK_HBM_GBS, 4), 'ms': round(mc_ms, 3),
                         'alg_bytes': round(mc_bytes), 'alg_bytes_definition': 'one pass over the float64 SDF (R^3 x 8 B) + 12 B per '
-                        'vertex and per face written', 'traffic': None})
+                        'vertex and per face written',
+                        # counter passes of tools/mc_prof.sh on a 250 k-vertex 512^3 body (not this run's volume): FETCH_SIZE
+                        # doubled (gfx950) + WRITE_SIZE, summed over the marching-cubes kernels of one call
+                        'traffic': prof_json.get('mc_hbm_bytes_per_call_512_body'),
+                        'traffic_source': 'profiles/traffic.json (tools/mc_prof.sh PMC passes on a 512^3 analytic body, an earlier run)'
+                        if prof_json.get('mc_hbm_bytes_per_call_512_body') else None})
                 # parity of the mesh the timed run produced: the same grid once more (not timed), marching cubes on a 128^3
                 # crop around the surface on the GPU and on the serial oracle - vertices and faces must agree bit for bit
                 r = mesh_util.reconstruction(netMR, dev, calib, args.genmesh_res, None, None, 0.5, use_octree=True,
