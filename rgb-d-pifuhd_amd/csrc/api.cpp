@@ -8,6 +8,9 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 
 #include <algorithm>
 #include <math.h>
@@ -442,24 +445,28 @@ inline bool write_all(int fd, const char *src, size_t left, int64_t off)
 }
 
 // 'v x y z r g b' lines of vertices [lo, hi) into o; returns the end
-inline char *format_vertex_lines(char *o, const double *verts, const double *colors, int64_t lo, int64_t hi)
+// (colours: float64 as the reference's array holds them, or the float32 values it was filled from - the same numbers)
+template <typename C>
+inline char *format_vertex_lines(char *o, const double *verts, const C *colors, int64_t lo, int64_t hi)
 {
     for (int64_t i = lo; i < hi; ++i) {
-        const double *v = verts + 3 * i, *c = colors + 3 * i;
+        const double *v = verts + 3 * i;
+        const C *c = colors + 3 * i;
         *o++ = 'v';
         for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, v[k]); }
-        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, c[k]); }
+        for (int k = 0; k < 3; ++k) { *o++ = ' '; o = put_fixed4(o, (double)c[k]); }
         *o++ = '\n';
     }
     return o;
 }
 
 // values of vertices [lo, hi) outside the fast formatter's range (each needs up to SLOW_CHARS characters)
-inline size_t count_slow_values(const double *verts, const double *colors, int64_t lo, int64_t hi)
+template <typename C>
+inline size_t count_slow_values(const double *verts, const C *colors, int64_t lo, int64_t hi)
 {
     size_t slow = 0;
     for (int64_t i = lo; i < hi; ++i)
-        for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs(colors[3 * i + k]) < 1e11);
+        for (int k = 0; k < 3; ++k) slow += !(fabs(verts[3 * i + k]) < 1e11) + !(fabs((double)colors[3 * i + k]) < 1e11);
     return slow;
 }
 
@@ -489,6 +496,50 @@ constexpr size_t OBJ_VERTEX_LINE = 168, OBJ_FACE_LINE = 40;      // upper bounds
 struct ObjWriter {
     int fd = -1;
     std::string path;
+    // vertices handed over in pieces (pifu_obj_vertices) while the caller is still computing the later ones: a queue of
+    // blocks in file order, formatted by a pool that starts with the first piece; a block's file offset is the end of its
+    // predecessor, known as soon as that one is FORMATTED.  The text goes to `path + ".part"`, renamed by pifu_obj_finish.
+    struct VBlock {
+        const double *v; const float *c; int64_t n;
+        std::atomic<int64_t> end{-1};          // file offset behind this block, once it is formatted
+        VBlock(const double *v_, const float *c_, int64_t n_) : v(v_), c(c_), n(n_) {}
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<VBlock> vblocks;
+    size_t vnext = 0;
+    bool vclosed = false, streaming = false;
+    std::vector<std::thread> vpool;
+    std::atomic<bool> vbad{false};
+
+    void format_vertices()
+    {
+        constexpr size_t FAST = (size_t)OBJ_BLOCK * OBJ_VERTEX_LINE + 64;
+        std::unique_ptr<char[]> own(new char[FAST]);               // uninitialised on purpose, re-used per block
+        std::unique_ptr<char[]> big;
+        for (;;) {
+            VBlock *b = nullptr, *prev = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return vnext < vblocks.size() || vclosed; });
+                if (vnext >= vblocks.size()) return;
+                b = &vblocks[vnext];
+                prev = vnext ? &vblocks[vnext - 1] : nullptr;     // element addresses of a deque survive push_back
+                ++vnext;
+            }
+            const size_t slow = count_slow_values(b->v, b->c, 0, b->n);
+            char *base = own.get();
+            if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
+            char *o = format_vertex_lines(base, b->v, b->c, 0, b->n);
+            int64_t off = 0;
+            if (prev) while ((off = prev->end.load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+            const size_t n = (size_t)(o - base);
+            b->end.store(off + (int64_t)n, std::memory_order_release);
+            if (!write_all(fd, base, n, off)) vbad.store(true);
+            big.reset();
+        }
+    }
+
     const int32_t *faces = nullptr;
     int64_t nfaces = 0, row_stride = 3, col_stride = 1;
     int64_t nblocks = 0;
@@ -530,10 +581,63 @@ extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nf
     return PIFU_OK;
 }
 
+extern "C" int pifu_obj_vertices(void *writer, const double *verts, const float *colors, int64_t count)
+{
+    PIFU_REQUIRE(writer && count >= 0 && ((verts && colors) || count == 0), PIFU_ERR_INVALID, "pifu_obj_vertices: bad argument");
+    ObjWriter *w = (ObjWriter *)writer;
+    if (!w->streaming) {
+        const std::string part = w->path + ".part";
+        const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_obj_vertices: cannot open %s", part.c_str());
+        w->fd = fd;
+        w->streaming = true;
+        const int nthreads = std::max(2, obj_threads(1 << 20) / 2);     // beside the face formatters and the caller's launches
+        for (int t = 0; t < nthreads; ++t) w->vpool.emplace_back([w]() { w->format_vertices(); });
+    }
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        for (int64_t lo = 0; lo < count; lo += OBJ_BLOCK)
+            w->vblocks.emplace_back(verts + 3 * lo, colors + 3 * lo, std::min(OBJ_BLOCK, count - lo));
+    }
+    w->cv.notify_all();
+    return PIFU_OK;
+}
+
 extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts)
 {
     PIFU_REQUIRE(writer, PIFU_ERR_INVALID, "pifu_obj_finish: null writer");
     std::unique_ptr<ObjWriter> w((ObjWriter *)writer);
+    if (w->streaming) {                                 // the vertices came through pifu_obj_vertices
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->vclosed = true;
+        }
+        w->cv.notify_all();
+        for (auto &th : w->vpool) th.join();
+        for (auto &th : w->pool) th.join();
+        const std::string part = w->path + ".part";
+        const bool args_ok = nverts < 0 || (nverts == 0 && !verts && !colors);
+        bool bad = w->vbad.load();
+        if (nverts >= 0 && args_ok && !bad) {
+            const int64_t vbytes = w->vblocks.empty() ? 0 : w->vblocks.back().end.load();
+            int64_t off = vbytes;
+            for (int64_t b = 0; b < w->nblocks && !bad; ++b) {          // the face blocks were formatted long ago: plain writes
+                if (!write_all(w->fd, w->text[b].get(), w->len[b], off)) bad = true;
+                off += (int64_t)w->len[b];
+                w->text[b].reset();
+            }
+        }
+        if (close(w->fd) != 0) bad = true;
+        if (nverts < 0 || bad || !args_ok) {            // abandoned or failed: the destination is left as it was
+            (void)unlink(part.c_str());
+            PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: the vertices of this writer were streamed; finish it "
+                         "with (NULL, NULL, 0)");
+            PIFU_REQUIRE(nverts < 0, PIFU_ERR_INVALID, "pifu_obj_finish: write error on %s", part.c_str());
+            return PIFU_OK;
+        }
+        PIFU_REQUIRE(rename(part.c_str(), w->path.c_str()) == 0, PIFU_ERR_INVALID, "pifu_obj_finish: cannot rename %s", part.c_str());
+        return PIFU_OK;
+    }
     if (nverts < 0) {                                   // abandon: wait for the face formatters, write nothing
         for (auto &th : w->pool) th.join();
         return PIFU_OK;

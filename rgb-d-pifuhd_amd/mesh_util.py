@@ -319,18 +319,38 @@ class ObjFile:
         if f.dtype != np.int32 or f.ndim != 2 or f.shape[1] != 3 or f.strides[0] % 4 or f.strides[1] % 4:
             f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
         self._faces = f                                  # kept alive until finish(): the worker threads read it
+        self._keep, self._streamed = [], False
         self._h = C.c_void_p()
         _lib.call('pifu_obj_begin', str(mesh_path).encode(), f.ctypes.data_as(C.c_void_p), len(f), f.strides[0] // 4,
                   f.strides[1] // 4, C.byref(self._h))
 
-    def finish(self, verts, colors):
+    def add_vertices(self, verts, colors32):
+        """The next vertices of the file (float64 [n,3]) with their colours as the float32 values the reference copies into
+        its float64 colour array; formatted in the background while the caller computes the following ones."""
         v = np.ascontiguousarray(verts, dtype=np.float64)
-        c = np.ascontiguousarray(colors, dtype=np.float64)
+        c = np.ascontiguousarray(colors32, dtype=np.float32)
+        if v.shape != c.shape or v.ndim != 2 or v.shape[1] != 3:
+            raise ValueError('add_vertices: verts and colours must both be [n, 3]')
+        self._keep.append((v, c))                        # read by the worker threads until finish()
+        _lib.call('pifu_obj_vertices', self._h, v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(v))
+        self._streamed = True
+
+    def finish(self, verts=None, colors=None):
+        """Write the file: with the vertices given here (float64 colours, `save_obj_mesh_with_color`'s arguments), or - after
+        `add_vertices` - with the ones already handed over."""
         h, self._h = self._h, None
         try:
-            _lib.call('pifu_obj_finish', h, v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(v))
+            if self._streamed:
+                if verts is not None or colors is not None:
+                    raise ValueError('finish(): the vertices of this file were already handed over by add_vertices()')
+                _lib.call('pifu_obj_finish', h, None, None, 0)
+            else:
+                v = np.ascontiguousarray(verts, dtype=np.float64)
+                c = np.ascontiguousarray(colors, dtype=np.float64)
+                _lib.call('pifu_obj_finish', h, v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(v))
         finally:
             self._faces = None
+            self._keep = []
 
     def __del__(self):                                   # an abandoned writer (exception between the two steps)
         if getattr(self, '_h', None):

@@ -9,6 +9,7 @@ at -1; a vertex count that is a multiple of 50 000 raises like the reference doe
 from __future__ import annotations
 
 import os
+import threading
 import time
 
 import numpy as np
@@ -54,6 +55,30 @@ def _normal_spans(n_verts, interval=50000):
 
 
 _copy_streams = {}
+_pinned = {}
+
+
+def _copy_stream(dev):
+    dev = torch.device(dev)
+    side = _copy_streams.get(dev)
+    if side is None:
+        side = _copy_streams[dev] = torch.cuda.Stream(dev)
+    return side
+
+
+def _pinned_rows(n, dev):
+    """float32 [n, 3] view of a pinned host buffer that is kept (and grown) across calls."""
+    buf = _pinned.get('rows')
+    if buf is None or buf.shape[0] < n:
+        buf = _pinned['rows'] = torch.empty(max(n, 1), 3, dtype=torch.float32, pin_memory=True)
+    return buf[:n]
+
+
+def _span_groups(spans, ngroups):
+    """Vertex ranges (left, right) made of whole consecutive spans, `ngroups` of near-equal length (fewer when there are
+    fewer spans): the units of the colour-loop pipeline."""
+    per = max((len(spans) + ngroups - 1) // ngroups, 1)
+    return [(spans[i][0], spans[min(i + per, len(spans)) - 1][1]) for i in range(0, len(spans), per)]
 
 
 def _upload_beside(t, dev):
@@ -62,9 +87,7 @@ def _upload_beside(t, dev):
     dev = torch.device(dev)
     if t.device == dev:
         return t
-    side = _copy_streams.get(dev)
-    if side is None:
-        side = _copy_streams[dev] = torch.cuda.Stream(dev)
+    side = _copy_stream(dev)
     cur = torch.cuda.current_stream(dev)
     with torch.cuda.stream(side):
         out = t.to(device=dev, non_blocking=True)
@@ -146,14 +169,43 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
                 (pdist.shard_range(len(spans), ws, rk)[:2] for rk in range(ws)) if j1 > j0]
         color32 = pdist.gather_runs(runs, mine, normals_of, 3, dev)
+        color = np.zeros(verts.shape)
+        color[:color32.shape[0]] = color32.cpu().numpy()
+        t4 = mark()
+        if obj is not None:
+            obj.finish(verts, color)                              # save_obj_mesh_with_color (mesh_util.py:189-198)
     else:
-        color32 = normals_of(0, spans[-1][1])
-    color = np.zeros(verts.shape)
-    color[:color32.shape[0]] = color32.cpu().numpy()
-    t4 = mark()
-
-    if obj is not None:
-        obj.finish(verts, color)                                  # save_obj_mesh_with_color (mesh_util.py:189-198)
+        # the colour loop as a pipeline: the calc_normal calls go to the GPU in a few groups of whole 50 000-vertex calls;
+        # each group's colours cross to pinned host memory on the copy stream as soon as they exist, and the OBJ writer
+        # formats that group's vertex lines on its own threads while the GPU works on the next group
+        n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
+        host_col = _pinned_rows(len(verts), dev)
+        host_col[n_col:].zero_()
+        host_np = host_col.numpy()
+        side, cur = _copy_stream(dev), torch.cuda.current_stream(dev)
+        done = []
+        for (l, r) in _span_groups(spans, 8):
+            col_d = normals_of(l, r).contiguous()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                host_col[l:r].copy_(col_d, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            col_d.record_stream(side)
+            done.append((l, r, ev))
+        for (l, r, ev) in done:
+            ev.synchronize()
+            if obj is not None:
+                obj.add_vertices(verts[l:r], host_np[l:r])
+        t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
+        if obj is not None:
+            obj.add_vertices(verts[n_col:], host_np[n_col:])
+        color = np.zeros(verts.shape)
+        filler = threading.Thread(target=lambda: color.__setitem__(slice(0, n_col), host_np[:n_col]))
+        filler.start()                                            # the float64 colour array gen_mesh returns, beside the file write
+        if obj is not None:
+            obj.finish()
+        filler.join()
     if png_thread is not None:
         png_thread.join()
     t5 = time.perf_counter()

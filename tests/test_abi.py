@@ -100,6 +100,23 @@ def test_obj_writer_host_only(lib, tmp_path):
     w = mesh_util.ObjFile(str(p), f[:0])
     w.finish(v[:0], c[:0])
     assert p.read_text() == ''
+    # the three-step form of gen_mesh's colour-loop pipeline: vertices handed over in pieces (any sizes, also empty and larger
+    # than a writer block) with float32 colours - the values the reference copies into its float64 colour array - while
+    # "later" pieces do not exist yet; same bytes as the one-call writer on the float64 copy of those colours
+    c32 = c.astype(np.float32)
+    want = O.obj_text(v, f[:, ::-1], c32.astype(np.float64))
+    w = mesh_util.ObjFile(str(p), f[:, ::-1])
+    cuts = [0, 1, 1, 7, 16384, 16385, 40001, len(v)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        w.add_vertices(v[a:b], c32[a:b])
+    assert not p.exists() or p.read_text() != want               # nothing under the final name before finish()
+    w.finish()
+    assert p.read_text() == want and not (tmp_path / 'a.obj.part').exists()
+    # abandoned mid-stream: the previous file stays, the partial one goes
+    w = mesh_util.ObjFile(str(p), f)
+    w.add_vertices(v[:100], c32[:100])
+    del w
+    assert p.read_text() == want and not (tmp_path / 'a.obj.part').exists()
     # a writer abandoned between the two steps (an exception in the colour loop) leaves the previous file as it was, and
     # creates none where there was none - the reference writes only once everything has succeeded
     p.write_text('previous result\n')
