@@ -620,12 +620,26 @@ extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *
         bool bad = w->vbad.load();
         if (nverts >= 0 && args_ok && !bad) {
             const int64_t vbytes = w->vblocks.empty() ? 0 : w->vblocks.back().end.load();
-            int64_t off = vbytes;
-            for (int64_t b = 0; b < w->nblocks && !bad; ++b) {          // the face blocks were formatted long ago: plain writes
-                if (!write_all(w->fd, w->text[b].get(), w->len[b], off)) bad = true;
-                off += (int64_t)w->len[b];
-                w->text[b].reset();
-            }
+            // the face blocks were formatted long ago: their offsets are a prefix sum, the writes go out in parallel
+            std::vector<int64_t> off((size_t)w->nblocks + 1, vbytes);
+            for (int64_t b = 0; b < w->nblocks; ++b) off[b + 1] = off[b] + (int64_t)w->len[b];
+            std::atomic<int64_t> next{0};
+            std::atomic<bool> fbad{false};
+            std::vector<std::thread> pool;
+            const int fd = w->fd;
+            ObjWriter *wp = w.get();
+            const int nthreads = w->nblocks ? obj_threads(w->nblocks) : 0;
+            for (int t = 0; t < nthreads; ++t)
+                pool.emplace_back([&, wp, fd]() {
+                    for (;;) {
+                        const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+                        if (b >= wp->nblocks) break;
+                        if (!write_all(fd, wp->text[b].get(), wp->len[b], off[b])) fbad.store(true);
+                        wp->text[b].reset();
+                    }
+                });
+            for (auto &th : pool) th.join();
+            bad = fbad.load();
         }
         if (close(w->fd) != 0) bad = true;
         if (nverts < 0 || bad || !args_ok) {            // abandoned or failed: the destination is left as it was

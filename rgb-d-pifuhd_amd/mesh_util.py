@@ -234,6 +234,27 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
         return -1
 
 
+_pinned = {}
+_copy_streams = {}
+
+
+def copy_stream(dev):
+    """One side stream per device for transfers that should not queue behind (or in front of) the compute stream's kernels."""
+    dev = torch.device(dev)
+    side = _copy_streams.get(dev)
+    if side is None:
+        side = _copy_streams[dev] = torch.cuda.Stream(dev)
+    return side
+
+
+def pinned_rows(tag, n, dtype):
+    """[n, 3] view of a pinned host buffer kept (and grown) across calls, one per tag."""
+    buf = _pinned.get(tag)
+    if buf is None or buf.shape[0] < n or buf.dtype != dtype:
+        buf = _pinned[tag] = torch.empty(max(n, 1), 3, dtype=dtype, pin_memory=True)
+    return buf[:n]
+
+
 # ------------------------------------------------------------------------------------------------
 # Generic host-callback variants (same signatures as the reference).  The octree bookkeeping still runs
 # in the HIP kernels; only `eval_func` (numpy in, numpy out) is the caller's.

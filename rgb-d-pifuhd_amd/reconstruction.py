@@ -17,22 +17,22 @@ import torch
 
 from numpy.linalg import inv
 
-from .mesh_util import ObjFile, reconstruction, save_obj_mesh_with_color
+from .mesh_util import ObjFile, copy_stream, pinned_rows, reconstruction, save_obj_mesh_with_color
 from .nets import index
 
 
 def _save_debug_png(path, image_tensor_global, background=False):
-    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`).  The pixels are fetched here; with
-    `background=True` the PNG encoding (zlib, GIL released) runs on a thread that the caller joins before returning."""
+    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`).  With `background=True` the pixel fetch and
+    the PNG encoding (zlib, GIL released) run on a thread that the caller joins before returning."""
     try:
         from PIL import Image
     except Exception:          # pragma: no cover - PIL is optional plumbing
         return None
     strip = torch.cat([image_tensor_global[v, :3] for v in range(image_tensor_global.shape[0])], 2)      # [3, H, n*W]
     arr = (strip.detach().permute(1, 2, 0) * 0.5 + 0.5) * 255.0
-    tiles = np.clip(np.rint(arr.cpu().numpy()), 0, 255).astype(np.uint8)
 
-    def encode():
+    def encode():                                                 # the fetch waits for the encoders only: also off the caller's path
+        tiles = np.clip(np.rint(arr.cpu().numpy()), 0, 255).astype(np.uint8)
         Image.fromarray(tiles).save(path, compress_level=1)      # cv2.imwrite's default PNG compression level is 1 too
     if not background:
         encode()
@@ -54,24 +54,19 @@ def _normal_spans(n_verts, interval=50000):
     return spans
 
 
-_copy_streams = {}
-_pinned = {}
-
-
-def _copy_stream(dev):
+def _upload_beside(t, dev):
+    """`t.to(dev)` issued on the copy stream, so that the transfer does not queue behind the kernels already issued on the
+    current stream; the current stream waits for it."""
     dev = torch.device(dev)
-    side = _copy_streams.get(dev)
-    if side is None:
-        side = _copy_streams[dev] = torch.cuda.Stream(dev)
-    return side
-
-
-def _pinned_rows(n, dev):
-    """float32 [n, 3] view of a pinned host buffer that is kept (and grown) across calls."""
-    buf = _pinned.get('rows')
-    if buf is None or buf.shape[0] < n:
-        buf = _pinned['rows'] = torch.empty(max(n, 1), 3, dtype=torch.float32, pin_memory=True)
-    return buf[:n]
+    if t.device == dev:
+        return t
+    side = copy_stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        out = t.to(device=dev, non_blocking=True)
+    cur.wait_stream(side)
+    out.record_stream(cur)
+    return out
 
 
 def _span_groups(spans, ngroups):
@@ -79,21 +74,6 @@ def _span_groups(spans, ngroups):
     fewer spans): the units of the colour-loop pipeline."""
     per = max((len(spans) + ngroups - 1) // ngroups, 1)
     return [(spans[i][0], spans[min(i + per, len(spans)) - 1][1]) for i in range(0, len(spans), per)]
-
-
-def _upload_beside(t, dev):
-    """`t.to(dev)` issued on a copy stream of its own, so that the transfer does not queue behind the kernels already
-    issued on the current stream; the current stream waits for it."""
-    dev = torch.device(dev)
-    if t.device == dev:
-        return t
-    side = _copy_stream(dev)
-    cur = torch.cuda.current_stream(dev)
-    with torch.cuda.stream(side):
-        out = t.to(device=dev, non_blocking=True)
-    cur.wait_stream(side)
-    out.record_stream(cur)
-    return out
 
 
 class _Subject:
@@ -118,7 +98,7 @@ class _Subject:
 
 
 def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None,
-             sharded=False):
+             sharded=False, _pipeline=True):
     """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.
 
     `sharded=True` (not in the reference, which is single-device): every rank of the initialised
@@ -132,7 +112,9 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
 
     def mark():
         if timings is not None:
-            torch.cuda.synchronize(dev)      # phase times are only meaningful once the queued kernels have finished
+            # phase times are only meaningful once the queued kernels have finished; the COMPUTE stream is waited for, not
+            # the copy stream, whose transfers are meant to run beside the next phase
+            torch.cuda.current_stream(dev).synchronize()
         return time.perf_counter()
     t0 = mark()
     subj = _Subject(net, data)
@@ -141,22 +123,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
 
-    # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
-    # like the reference (reconstruction.py:56)
-    verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
-                                                   use_octree=use_octree, num_samples=5000, sharded=sharded,
-                                                   return_device_verts=True)
-    t3 = mark()
-    obj = ObjFile(save_path, faces) if rank == 0 else None       # the face lines are formatted while the colours are computed
-    # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()` (reconstruction.py:57) without the host round trip:
-    # the float64 vertices are still on the device, and the float64 -> float32 cast rounds the same way there
-    verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
-
-    spans = _normal_spans(len(verts))
-    if any(r == l for (l, r) in spans):
-        # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
-        raise RuntimeError('calc_normal on an empty vertex slice')
-
+    spans_check = lambda spans: any(r == l for (l, r) in spans)      # noqa: E731
     # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
     # (`reconstruction.py:58-70`), several of them per kernel launch
     def normals_of(left, right):
@@ -164,6 +131,18 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
 
     if exchange:
+        # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
+        # like the reference (reconstruction.py:56)
+        verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
+                                                       use_octree=use_octree, num_samples=5000, sharded=True,
+                                                       return_device_verts=True)
+        t3 = mark()
+        obj = ObjFile(save_path, faces) if rank == 0 else None   # the face lines are formatted while the colours are computed
+        verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
+        spans = _normal_spans(len(verts))
+        if spans_check(spans):
+            # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+            raise RuntimeError('calc_normal on an empty vertex slice')
         i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
         mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
         runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
@@ -175,16 +154,33 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         if obj is not None:
             obj.finish(verts, color)                              # save_obj_mesh_with_color (mesh_util.py:189-198)
     else:
-        # the colour loop as a pipeline: the calc_normal calls go to the GPU in a few groups of whole 50 000-vertex calls;
-        # each group's colours cross to pinned host memory on the copy stream as soon as they exist, and the OBJ writer
-        # formats that group's vertex lines on its own threads while the GPU works on the next group
+        # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
+        # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
+        # calc_normal calls go to the GPU in a few groups of whole 50 000-vertex calls; each group's colours cross to pinned
+        # host memory on the copy stream as soon as they exist, and the OBJ writer formats that group's vertex lines on its
+        # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
+        # asynchronous transfers into pinned buffers beside the colour loop - the extra 200 MB of host copies they need to
+        # hand arrays of their own back to the caller cost more than the 15 ms of transfer they hide.)
+        # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
+        # reference (reconstruction.py:56)
+        verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
+                                                       use_octree=use_octree, num_samples=5000, sharded=sharded,
+                                                       return_device_verts=True)
+        t3 = mark()
+        obj = ObjFile(save_path, faces)                           # the face lines are formatted while the colours are computed
+        n_verts = len(verts)
+        spans = _normal_spans(n_verts)
+        if spans_check(spans):
+            raise RuntimeError('calc_normal on an empty vertex slice')
+        verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
         n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
-        host_col = _pinned_rows(len(verts), dev)
+        host_col = pinned_rows('colours', n_verts, torch.float32)
         host_col[n_col:].zero_()
         host_np = host_col.numpy()
-        side, cur = _copy_stream(dev), torch.cuda.current_stream(dev)
+        side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
         done = []
-        for (l, r) in _span_groups(spans, 8):
+        # (_pipeline=False - tools/genmesh_ab.py - is the unpipelined form for A/B timing: one group, vertex lines at the end)
+        for (l, r) in _span_groups(spans, 8 if _pipeline else 1):
             col_d = normals_of(l, r).contiguous()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
@@ -193,19 +189,14 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
                 ev.record(side)
             col_d.record_stream(side)
             done.append((l, r, ev))
+        color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
         for (l, r, ev) in done:
             ev.synchronize()
-            if obj is not None:
-                obj.add_vertices(verts[l:r], host_np[l:r])
+            obj.add_vertices(verts[l:r], host_np[l:r])
+            color[l:r] = host_np[l:r]                             # while the GPU computes the next group
         t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
-        if obj is not None:
-            obj.add_vertices(verts[n_col:], host_np[n_col:])
-        color = np.zeros(verts.shape)
-        filler = threading.Thread(target=lambda: color.__setitem__(slice(0, n_col), host_np[:n_col]))
-        filler.start()                                            # the float64 colour array gen_mesh returns, beside the file write
-        if obj is not None:
-            obj.finish()
-        filler.join()
+        obj.add_vertices(verts[n_col:], host_np[n_col:])
+        obj.finish()
     if png_thread is not None:
         png_thread.join()
     t5 = time.perf_counter()
