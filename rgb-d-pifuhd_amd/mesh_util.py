@@ -184,7 +184,7 @@ def transform_verts(ctx, verts_d, trans_mat):
     out_d = torch.empty(n, 3, device=verts_d.device, dtype=torch.float64)
     _lib.call('pifu_transform_verts', ctx.h, _ptr(verts_d), n, rows.ctypes.data_as(C.c_void_p), _ptr(out_d),
               _stream_ptr(ctx.device))
-    return out_d.cpu().numpy(), out_d
+    return to_host(out_d), out_d
 
 
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
@@ -213,7 +213,7 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
             verts_d, faces_d = pdist.marching_cubes_sharded(ctx, sdf, thresh)
         else:
             verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
-        faces = faces_d.cpu().numpy()
+        faces = to_host(faces_d)
         _, calib_inv = calib_pair(calib_tensor)
         mat = np.eye(4)
         mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
@@ -245,6 +245,40 @@ def copy_stream(dev):
     if side is None:
         side = _copy_streams[dev] = torch.cuda.Stream(dev)
     return side
+
+
+_slabs = []          # [pinned uint8 tensor, weak reference to the array last handed out from it]
+POOL_RESULTS = True  # False: plain `.cpu().numpy()` results (tools/genmesh_ab.py times the difference)
+
+
+def to_host(t):
+    """Device tensor -> host array OF THE CALLER'S OWN, without a fresh pageable allocation per call (a 100 MB result costs
+    ~25 000 page faults plus a staged copy each time): the copy lands in a pinned slab, and the returned array is a view of
+    it.  A slab is handed out again only once the array it backed is gone - arrays and every view of them are tracked
+    through a weak reference, since numpy views keep their parent alive - so a caller that keeps a result keeps its memory;
+    when all slabs are in use (or the tensor is small) this is the plain `.cpu().numpy()`."""
+    import weakref
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes < (4 << 20) or not POOL_RESULTS:
+        return t.cpu().numpy()
+    slot = None
+    for s in _slabs:
+        if s[1]() is None:
+            if s[0].numel() < nbytes:
+                s[0] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=True)      # free but too small: regrow
+            slot = s
+            break
+    if slot is None:
+        if len(_slabs) >= 6:
+            return t.cpu().numpy()
+        slot = [torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=True), lambda: None]
+        _slabs.append(slot)
+    view = slot[0][:nbytes].view(t.dtype).view(t.shape)
+    view.copy_(t)
+    arr = view.numpy()
+    slot[1] = weakref.ref(arr)
+    return arr
 
 
 def pinned_rows(tag, n, dtype):

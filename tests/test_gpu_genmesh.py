@@ -375,3 +375,38 @@ def test_gen_mesh_imgcolor_plus(tmp_path, capsys):
     assert np.array_equal(verts, want[0]) and np.array_equal(faces, want[1]) and np.array_equal(rgba, want[2])
     v1, c1, f1 = reconstruction.read_obj_with_color(path)
     assert np.array_equal(f1, faces) and np.allclose(v1, verts, atol=5e-5) and np.allclose(c1, rgba[:, :3] / 255.0, atol=5e-5)
+
+
+def test_result_arrays_are_the_callers_own():
+    """`reconstruction()` hands its vertex / face arrays out of pinned slabs that it reuses (`mesh_util.to_host`): a result
+    the caller still holds - directly or through a view - must never be overwritten by a later call, and memory is taken
+    back only once the caller has dropped the arrays."""
+    import gc
+    from pifuhd_amd import mesh_util, nets
+    sd, oc, of = golden_nets()
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(9)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+
+    def run(R):
+        r = mesh_util.reconstruction(netMR, 'cuda', calib_tensor(), R, None, None, 0.5, use_octree=True, num_samples=5000)
+        assert r != -1
+        return r[0], r[1]
+    va, fa = run(128)
+    assert va.nbytes > (4 << 20)                                   # large enough to come out of a slab
+    keep_v, keep_f = va.copy(), fa.copy()
+    view_only = fa[:, ::-1]                                        # a view alone must keep the memory, too
+    addr = {va.ctypes.data, fa.ctypes.data}
+    del fa
+    vb, fb = run(128)                                              # while the first result is still referenced
+    assert not ({vb.ctypes.data, fb.ctypes.data} & addr)
+    assert np.array_equal(va, keep_v) and np.array_equal(view_only[:, ::-1], keep_f)
+    assert np.array_equal(vb, keep_v) and np.array_equal(fb, keep_f)
+    vc, fc_ = run(96)                                              # a third, different result: still nothing is clobbered
+    assert np.array_equal(va, keep_v) and np.array_equal(vb, keep_v) and np.array_equal(view_only[:, ::-1], keep_f)
+    del va, view_only, vb, fb, vc, fc_
+    gc.collect()
+    vd, fd = run(128)                                              # everything dropped: the slabs are taken back
+    assert {vd.ctypes.data, fd.ctypes.data} & addr
+    assert np.array_equal(vd, keep_v) and np.array_equal(fd, keep_f)

@@ -16,9 +16,12 @@ synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3)
 with tempfile.TemporaryDirectory() as td:
     for k, mode in enumerate((True, False)):
         recon.gen_mesh(RES, netMR, 'cuda', data, os.path.join(td, 'w%d.obj' % k), _pipeline=mode)     # warm both forms
+    from pifuhd_amd import mesh_util
     for rep in range(4):
-        for mode in (True, False):
+        for mode, pool in ((True, True), (False, True), (True, False)):
+            mesh_util.POOL_RESULTS = pool
             t = {}
             recon.gen_mesh(RES, netMR, 'cuda', data, os.path.join(td, 'm%d_%d.obj' % (rep, mode)), timings=t, _pipeline=mode)
-            print('pipeline' if mode else 'one group', {k: round(v, 4) for k, v in t.items() if k.endswith('_s')}, flush=True)
+            print(('pipeline ' if mode else 'one group') + (' + pooled results' if pool else ' + pageable results'),
+                  {k: round(v, 4) for k, v in t.items() if k.endswith('_s')}, flush=True)
             os.remove(os.path.join(td, 'm%d_%d.obj' % (rep, mode)))
