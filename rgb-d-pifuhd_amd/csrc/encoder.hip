@@ -139,7 +139,7 @@ struct ConvDmaArgs {
 };
 
 template <int TN>
-__global__ __launch_bounds__(256, 3) void k_conv_dma(const ConvDmaArgs a)
+__device__ __forceinline__ void conv_dma_tile(const ConvDmaArgs &a, const int block_id)
 {
     constexpr int WN = TN == 32 ? 1 : 2, WM = 4 / WN;          // wave grid
     constexpr int MT = (BM / WM) / 32, NT = (TN / WN) / 32;    // 32 x 32 accumulators per wave
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(const ConvDmaArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int split = blockIdx.x / a.tiles_per_split, bt = blockIdx.x - split * a.tiles_per_split;
+    const int split = block_id / a.tiles_per_split, bt = block_id - split * a.tiles_per_split;
     const int xcd = bt & 7, slot = bt >> 3;
     const int tile_n = slot % a.ntn;
     const int tile_m = (slot / a.ntn) * 8 + xcd;
@@ -301,6 +301,25 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(const ConvDmaArgs a)
             dst[1] = qd;
         }
     }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void k_conv_dma(const ConvDmaArgs a)
+{
+    conv_dma_tile<TN>(a, blockIdx.x);
+}
+
+// The four output-parity classes of a transposed convolution (same tile grid, different taps / weights / output offsets) as
+// ONE launch, class = blockIdx.y: at 128^2 -> 256^2 and 256^2 -> 512^2 a class alone is 512 blocks of 4 - 16 K steps - two
+// thirds of the chip's block slots, done before it is warm (254 / 228 us for the four launches of 9.7 GFLOP).
+struct ConvDma4 {
+    ConvDmaArgs a[4];
+};
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void k_conv_dma4(const ConvDma4 m)
+{
+    conv_dma_tile<TN>(m.a[blockIdx.y], blockIdx.x);
 }
 
 // split-K epilogue of k_conv_dma: Y = sum_s part[s] (fixed order) + bias (+ residual), with the conv's output pixel mapping
@@ -568,6 +587,8 @@ __global__ void k_pack_input(const float *img, int Cimg, int H, int W, const flo
 // InstanceNorm + ReLU prologue applied once per input value instead of once per tap - and the 3 x 49 x 16 weights in LDS
 // (pixel stride 20 floats: conflict-free ds_read_b128), then every thread runs its 49 taps from LDS.  (The one-thread-per-
 // pixel version re-read and re-normalised every input value 49 times from global memory: 1.3 ms per 512 x 512 image.)
+// (Tried in round 3: the tap weights by block-uniform scalar loads instead of LDS - 4 instead of 16 ds_read_b128 per 48 FMAs;
+// slower, 323 -> 385 us: the scalar loads' latency sits in front of every tap.)
 __global__ __launch_bounds__(256) void k_conv7_to3_tanh(const float *X, int ldx, int H, int W, int Cin, const float *scale,
                                                         const float *shift, const float *Wt /* [3][49][Cin] */, const float *bias,
                                                         float *out_nchw)
@@ -899,7 +920,8 @@ float *prepare_input(EncState &S, const Tensor &x, const Affine &act, int Cp, in
 }
 
 // `stat` (may be null): receives the statistics partials of the stored values, if this launch can produce them (no split-K)
-void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr, int stat_class = 0, int stat_classes = 1)
+// fills the derived fields of `a` (tile grid, split-K plan and workspace, statistics target); returns the grid size
+unsigned plan_conv_dma(EncState &S, ConvDmaArgs &a, int tn, Tensor *stat, int stat_class, int stat_classes)
 {
     a.ntm = (a.nrows + BM - 1) / BM;
     a.ntn = (a.cout + tn - 1) / tn;
@@ -936,10 +958,15 @@ void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr,
         stat->stat = nullptr;
         stat->stat_nb = 0;
     }
-    const unsigned grid = (unsigned)tiles * nsplit;
+    return (unsigned)tiles * nsplit;
+}
+
+void launch_conv_dma(EncState &S, ConvDmaArgs a, int tn, Tensor *stat = nullptr, int stat_class = 0, int stat_classes = 1)
+{
+    const unsigned grid = plan_conv_dma(S, a, tn, stat, stat_class, stat_classes);
     if (tn == 64) hipLaunchKernelGGL(k_conv_dma<64>, dim3(grid), dim3(256), 0, S.cur->st, a);
     else hipLaunchKernelGGL(k_conv_dma<32>, dim3(grid), dim3(256), 0, S.cur->st, a);
-    if (nsplit > 1) {
+    if (a.nsplit > 1) {
         const size_t threads = (size_t)a.nrows * (a.ldp / 4);
         hipLaunchKernelGGL(k_conv_dma_reduce, dim3(nblk(threads, 256)), dim3(256), 0, S.cur->st, a);
     }
@@ -1000,6 +1027,7 @@ void conv_transpose2d(EncState &S, const std::string &wname, const std::string &
         const float *bias = packed_bias(S, bname, cout_pad, true);
         unsigned p_bytes = 0;
         const float *P = prepare_input(S, x, act, Cp, 0, Hp, Wp, false, &p_bytes);
+        ConvDma4 four{};
         for (int py = 0; py < 2; ++py)
             for (int px = 0; px < 2; ++px) {
                 // oy = 2 ry + py: input row ry uses ky = 1 (py == 0) or ky = 2 (py == 1); input row ry + 1 uses ky = 0 (py == 1)
@@ -1023,8 +1051,19 @@ void conv_transpose2d(EncState &S, const std::string &wname, const std::string &
                 }
                 a.Y = out.p; a.ldy = out.ld; a.cout = co;
                 a.os = 2; a.oy0 = py; a.ox0 = px; a.Wout = out.W;
-                launch_conv_dma(S, a, tn, &out, py * 2 + px, 4);
+                four.a[py * 2 + px] = a;
             }
+        // the classes share the tile grid; whether they are split along K depends on that grid only (the deepest class decides
+        // the split count of each, so it is looked at per class)
+        const int ntiles = ((x.H * x.W + BM - 1) / BM) * ((co + tn - 1) / tn);
+        if (ntiles >= 384) {            // no split-K in any class: one launch for all four
+            unsigned grid = 0;
+            for (int c = 0; c < 4; ++c) grid = plan_conv_dma(S, four.a[c], tn, &out, c, 4);
+            if (tn == 64) hipLaunchKernelGGL(k_conv_dma4<64>, dim3(grid, 4), dim3(256), 0, S.cur->st, four);
+            else hipLaunchKernelGGL(k_conv_dma4<32>, dim3(grid, 4), dim3(256), 0, S.cur->st, four);
+        } else {
+            for (int c = 0; c < 4; ++c) launch_conv_dma(S, four.a[c], tn, &out, c, 4);
+        }
     }
 }
 
