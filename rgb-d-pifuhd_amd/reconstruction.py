@@ -37,7 +37,6 @@ def _save_debug_png(path, image_tensor_global, background=False):
     if not background:
         encode()
         return None
-    import threading
     th = threading.Thread(target=encode)
     th.start()
     return th
@@ -123,7 +122,9 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
 
-    spans_check = lambda spans: any(r == l for (l, r) in spans)      # noqa: E731
+    def spans_check(spans):      # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+        return any(r == l for (l, r) in spans)
+
     # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
     # (`reconstruction.py:58-70`), several of them per kernel launch
     def normals_of(left, right):
@@ -283,8 +284,6 @@ def largest_component(verts, faces, device):
     for an edge nobody else uses opens its component; the faces around an edge that three or more faces share (they
     appear once vertices have been merged) are few and are counted per component here.  Raises IndexError when no
     component is watertight (`cc[0]` on an empty list in the reference)."""
-    import ctypes as C
-
     from . import _lib
     from .net_util import _ctx_cache
     from .nets import _ptr, _stream_ptr
