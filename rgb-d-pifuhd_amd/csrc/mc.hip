@@ -28,7 +28,8 @@ __device__ __constant__ const signed char COFF[8][3] = {{0, 0, 0}, {1, 0, 0}, {1
 // edge e joins corners {0,1,2,3,4,5,6,7,0,1,2,3}[e] and {1,2,3,0,5,6,7,4,4,5,6,7}[e]; its axis (0 = x, 1 = y, 2 = z) and the
 // offset of its lower endpoint are the immediates EDGE_AXIS_BITS / EDGE_BASE_BITS further down.  EDGE_NEEDZERO: the mask of
 // cell coordinates (bit0 x, bit1 y, bit2 z) that must be 0 for this cell to be the first one touching the edge
-__device__ __constant__ const signed char EDGE_NEEDZERO[12] = {2 | 4, 4, 4, 1 | 4, 2, 0, 0, 1, 1 | 2, 2, 0, 1};
+constexpr uint64_t EDGE_NEEDZERO_BITS = (6ull << 0) | (4ull << 3) | (4ull << 6) | (5ull << 9) | (2ull << 12) | (0ull << 15) | (0ull << 18) |
+                                        (1ull << 21) | (3ull << 24) | (2ull << 27) | (0ull << 30) | (1ull << 33);      // {2|4, 4, 4, 1|4, 2, 0, 0, 1, 1|2, 2, 0, 1}
 // interior-test table e:(p,q,(b0,b1),(c0,c1),(d0,d1))
 __device__ __constant__ const signed char TI[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7},
                                                       {3, 0, 2, 1, 6, 5, 7, 4}, {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2},
@@ -191,7 +192,7 @@ struct Vol {
     const uint8_t *brick;
     int b0, b1, b2;
     // 1 for every group of 256 consecutive cells of the serial scan that touches such a brick (k_mc_groups); the three
-    // classification passes give a block MC_GPB groups and skip the others without touching their cells
+    // counting pass gives a block a few groups (mc_groups_per_block) and skips the others without touching their cells
     const uint8_t *gflag;
     // slab mode (pifu_mc_slab_*): the volume holds node planes [zoff, zoff + n0) of a taller one.  Vertex ownership along
     // axis 0 and the axis-0 coordinate of the vertices refer to the tall volume; 0 for a whole volume
@@ -237,14 +238,26 @@ __device__ bool classify(const Vol &v, int64_t cell, CellInfo &ci, float *corner
     for (int i = 0; i < 8; ++i) mine[i * 256] = d[i];
     ci.nt = choose_tiling(Corners{mine, v.level}, index, &ci.row);
     const int zero_mask = (x == 0 ? 1 : 0) | (y == 0 ? 2 : 0) | (z + v.zoff == 0 ? 4 : 0);
+    // the triangle row (3 nt <= 36 edge ids): every byte is requested before the first one is looked at - one memory round
+    // trip instead of a chain of 3 nt dependent ones - and walked from registers (all indices static after unrolling)
+    const int nrow = 3 * ci.nt;
+    signed char rb[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) rb[k] = k < nrow ? ci.row[k] : (signed char)0;
     unsigned seen = 0;
-    for (int k = 0; k < 3 * ci.nt; ++k) {
-        const int e = ci.row[k];
-        if (seen & (1u << e)) continue;
-        seen |= 1u << e;
-        if (e == 12 || (EDGE_NEEDZERO[e] & ~zero_mask) == 0) {
-            ci.own |= (uint64_t)e << (4 * ci.nown);
-            ++ci.nown;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        if (k < nrow) {
+            const int e = rb[k];
+            if (!(seen & (1u << e))) {
+                seen |= 1u << e;
+                // EDGE_NEEDZERO as an immediate, 3 bits per edge (12: the centre vertex, always the cell's own)
+                const unsigned need = e == 12 ? 0u : (unsigned)((EDGE_NEEDZERO_BITS >> (3 * e)) & 7u);
+                if ((need & ~(unsigned)zero_mask) == 0) {
+                    ci.own |= (uint64_t)e << (4 * ci.nown);
+                    ++ci.nown;
+                }
+            }
         }
     }
     return true;
@@ -360,7 +373,9 @@ __global__ void k_mc_brick_combine(const Vol v, int nb0, int nb1, int nb2, const
     brick[b] = (pos && neg) ? 1 : 0;
 }
 
-constexpr int MC_GPB = 4;       // groups of 256 cells per block of the counting pass
+// groups of 256 cells per block of the counting pass: few, so that the surface regions spread over many blocks (512^3: 0.83 ms at
+// 32, 0.58 at 8 and at 4), more on the largest volumes, where a block per 1 024 cells is a million blocks (1024^3: 5.2 ms at 8, 6.2 at 4)
+inline int mc_groups_per_block(int64_t ngroups) { return ngroups > (int64_t)1 << 21 ? 8 : 4; }
 
 // which groups of 256 consecutive cells can hold a surface cell at all: one thread per group walks its cells brick by brick
 __global__ void k_mc_groups(const Vol v, int64_t ngroups, uint8_t *gflag)
@@ -393,12 +408,12 @@ struct SurfList {
 };
 
 // pass 1: group g covers cells [256 g, 256 g + 256) of the serial scan; per group (vertices << 32 | triangles) created,
-// and the records of its surface cells.  A block gathers the records of its MC_GPB groups in LDS and takes its place in the
-// list with ONE atomic (a device-wide counter is a fabric round trip per access: one per group made this pass 2x slower
-// than the classification itself), then copies them out with consecutive lanes on consecutive records.
+// and the records of its surface cells.  A block gathers the records of its groups in LDS and takes its place in the
+// list with ONE atomic per buffer-full, then copies them out with consecutive lanes on consecutive records.
 constexpr int MC_REC_CAP = 256;       // records buffered per block (7 KB); a fuller buffer is flushed before the next group
 
-__global__ __launch_bounds__(256) void k_mc_count(const Vol v, int64_t ngroups, uint64_t *blk_vt, const SurfList L, unsigned long long *nsurf)
+__global__ __launch_bounds__(256) void k_mc_count(const Vol v, int64_t ngroups, int gpb, uint64_t *blk_vt, const SurfList L,
+                                                  unsigned long long *nsurf)
 {
     __shared__ uint32_t sh[4];
     __shared__ uint32_t wcnt[4];
@@ -427,8 +442,8 @@ __global__ __launch_bounds__(256) void k_mc_count(const Vol v, int64_t ngroups, 
         nbuf = 0;
     };
 
-    for (int gi = 0; gi < MC_GPB; ++gi) {
-        const int64_t group = (int64_t)blockIdx.x * MC_GPB + gi;
+    for (int gi = 0; gi < gpb; ++gi) {
+        const int64_t group = (int64_t)blockIdx.x * gpb + gi;
         if (group >= ngroups) break;
         if (!v.gflag[group]) {                                   // block-uniform
             if (threadIdx.x == 0) blk_vt[group] = 0;
@@ -640,7 +655,8 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
         hipLaunchKernelGGL(k_mc_groups, dim3((unsigned)((a.nblocks + 255) / 256)), dim3(256), 0, st, v, a.nblocks, a.gflag);
         v.gflag = a.gflag;
         PIFU_HIP(hipMemsetAsync(a.totals, 0, 32, st));
-        hipLaunchKernelGGL(k_mc_count, dim3((unsigned)((a.nblocks + MC_GPB - 1) / MC_GPB)), dim3(256), 0, st, v, a.nblocks, a.blk_vt,
+        const int gpb = mc_groups_per_block(a.nblocks);
+        hipLaunchKernelGGL(k_mc_count, dim3((unsigned)((a.nblocks + gpb - 1) / gpb)), dim3(256), 0, st, v, a.nblocks, gpb, a.blk_vt,
                            a.list, (unsigned long long *)(a.totals + 2));
         scan_u64(a.blk_vt, a.nblocks, a.totals, a.tile_sums, st);
         char *pin = (char *)ctx->pinned;
