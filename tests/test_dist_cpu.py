@@ -191,3 +191,33 @@ def test_shard_chunks_at_config5_scale():
         assert end == total
         per = -(-(-(-total // chunk)) // ws)                     # chunks per rank, rounded up
         assert max(counts) == per * chunk and min(counts) > (per - ws) * chunk      # only the last rank is short, by < ws chunks
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without RANK / WORLD_SIZE must start the ranks itself: a fresh `python -m
+    torch.distributed.run` child with this node's loop-back rendezvous, the bench script and the caller's own arguments,
+    whose return code it hands back - decided before torch or the GPU is touched (checked on the command it builds)."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                      # importing bench.py must not import torch.distributed work or the GPU
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, **kw):
+        seen['cmd'], seen['kw'] = cmd, kw
+        return Done()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '5', '--warmup', '2'])
+    assert bench.launch_ranks(4) == 7                   # the child's return code comes back
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    script = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[script + 1:] == ['--gpus', '4', '--steps', '5', '--warmup', '2']
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'          # set before the HIP runtime can load
