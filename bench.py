@@ -672,6 +672,21 @@ def main():
                 out['gen_mesh'] = {'error': repr(e)}
             finally:
                 _lib.call('pifu_profile_enable', h, 0)
+            # the same call with the MLP GEMMs on the opt-in fp16 x 3 split products (pifu_set_precision(ctx, 2): operands good
+            # to 2^-22, fp32 accumulation; ~3e-6 from the exact-fp32 path on the occupancy).  A side number, never the headline:
+            # the octree picks its points from values that differ in the sixth decimal, so the mesh may differ by a few cells
+            if not args.no_split_precision and 'error' not in out['gen_mesh']:
+                try:
+                    _lib.call('pifu_set_precision', h, 2)
+                    recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm_fp16x3.obj'))
+                    ts = {}
+                    recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'mesh_fp16x3.obj'), timings=ts)
+                    out['gen_mesh']['opt_in_fp16x3'] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ts.items()}
+                    log(f"gen_mesh with fp16x3 split products (opt-in): {ts.get('total_s'):.3f} s, {ts.get('n_verts')} vertices")
+                except Exception as e:
+                    out['gen_mesh']['opt_in_fp16x3'] = {'error': repr(e)}
+                finally:
+                    _lib.call('pifu_set_precision', h, 0)
             # the same call on a SMOOTHER subject: the MLP weights drawn at torch's stock scale (std 0.02 instead of the 0.16
             # that gives the headline subject its rough, multi-million-vertex surface).  Fewer points survive the octree and
             # fewer vertices need normals, so the per-image work (encoders) and the fixed costs weigh more - the other end of
