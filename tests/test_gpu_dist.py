@@ -368,3 +368,41 @@ def test_gen_mesh_1024_sharded_world2_with_slab_marching_cubes(tmp_path):
     if len(odd) == 0:
         assert chi % 2 == 0 and chi <= 2 * ncomp
     print(f'1024^3 sharded gen_mesh: V={V} F={F} E={E} chi={chi} components={ncomp} open_edges={len(odd)}')
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_gpu_line_carries_every_contract_field():
+    """`python bench.py` (N = 1) at reduced sizes: ONE JSON line with the contract's fields - metric / value / unit /
+    dtype / config.workload, `roofline` {bound, achieved, peak, unit, frac, traffic}, `cpu_baseline` {value, unit, cores,
+    kind, sample} - and the round-3 additions (`chunk_100000`, the canonical GEMM's `frac_at_measured_clock`, `config5_1024`,
+    the CPU gen_mesh baseline with the SDF difference of the whole multi-level octree field)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cmd = [sys.executable, 'bench.py', '--steps', '1', '--warmup', '1', '--res', '64', '--genmesh-res', '64', '--config5-res', '96',
+           '--batch-rows', '262144', '--cpu-seconds', '2', '--cpu-chunks', '4', '--cpu-genmesh-res', '64', '--cpu-genmesh-res2', '0',
+           '--canonical-steps', '1']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['metric'] == 'occupancy_queries_throughput' and d['unit'] == 'Mqueries/s' and d['value'] > 0
+    assert d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    ro = d['roofline']
+    assert ro['bound'] == 'mfma' and ro['unit'] == 'TFLOP/s' and ro['peak'] == 157.3 and 'traffic' in ro
+    assert abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-3 and ro['achieved'] > 0
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and cb['unit'] == 'Mqueries/s' and cb['sample']
+    assert d['parity_check_max_abs_diff'] < 1e-4
+    assert d['chunk_100000']['value'] > 0
+    assert d['canonical_path']['gemm_roofline']['frac_at_measured_clock'] > 0
+    assert d['canonical_path']['max_abs_diff_vs_headline_field'] < 1e-4
+    g = d['gen_mesh']
+    assert g['total_s'] > 0 and g['mc_check']['faces_bit_exact_vs_oracle'] and g['mc_check']['verts_bit_exact_vs_oracle']
+    assert g['config5_1024']['resolution'] == 96 and g['config5_1024']['n_verts'] > 0
+    cg = d['cpu_baseline_gen_mesh']
+    assert cg['resolution'] == 64 and cg['value'] > 0
+    assert cg['gpu_same_resolution']['max_abs_diff_sdf'] < 1e-4 and cg['gpu_same_resolution']['same_points_evaluated']
+    assert {x['bound'] for x in d['roofline_secondary']} >= {'hbm'}
