@@ -26,3 +26,11 @@ def _build_oracle_lib():
     if not os.path.exists(so):
         import subprocess
         subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')])
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _bounded_torch_threads():
+    """The torch-CPU oracle runs small per-chunk GEMMs: with every hardware thread of a 256-thread GPU host it is several
+    times slower than with 32 (bench.py measured the same), which made the parity suite take ten minutes."""
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))

@@ -596,7 +596,12 @@ def test_multi_level_network_octree_composition_vs_oracle(init):
         with torch.no_grad():
             return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib_t)[0, 0].numpy()
     stats = []
-    want = O.eval_grid_octree(R, cinv, field, chunk, init_resolution=init, stats=stats)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # torch-CPU on these small GEMMs is slower with every host thread
+    try:
+        want = O.eval_grid_octree(R, cinv, field, chunk, init_resolution=init, stats=stats)
+    finally:
+        torch.set_num_threads(threads)
     assert len(stats) == {64: 2, 16: 4}[init] and all(n > 0 for _, n in stats)
 
     # the fused device loop
