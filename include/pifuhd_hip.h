@@ -287,12 +287,17 @@ int pifu_write_obj(const char *path, const double *verts, const double *colors, 
  * nverts < 0 abandons the writer: the workers are joined, nothing is created or truncated - a run that fails between the
  * two calls leaves `path` as it was, like the reference, which only writes once the colours exist. */
 int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride, void **writer);
-/* Optional middle step, for callers whose vertex colours arrive in pieces (gen_mesh's colour loop, reconstruction.py:58-70):
- * the next `count` vertices of the file - verts HOST double [count][3], colors HOST float32 [count][3] (the float32 values
- * the reference copies into its float64 colour array: the same text) - are queued and formatted in the background while the
- * caller computes the following ones; both arrays must stay alive until pifu_obj_finish.  The text goes to `<path>.part`;
- * pifu_obj_finish(writer, NULL, NULL, 0) then appends the faces and renames it to `path` (nverts < 0: removes it). */
-int pifu_obj_vertices(void *writer, const double *verts, const float *colors, int64_t count);
+/* Optional middle steps, for callers that know every vertex POSITION long before the last COLOUR (gen_mesh: marching cubes,
+ * then the colour loop, reconstruction.py:56-72).  pifu_obj_layout declares the complete arrays - verts HOST double [nverts][3],
+ * colors HOST float32 [nverts][3] (the float32 values the reference copies into its float64 colour array: the same text), both
+ * alive until pifu_obj_finish, the colours still to be filled in.  A colour in [0, 10) prints as 6 characters, so the positions
+ * alone fix the file offset of every vertex block and of the face section: the face blocks are written in place at once, and
+ * pifu_obj_ready(writer, upto) - "the colours of vertices [0, upto) are valid" - releases the vertex blocks below `upto` to be
+ * formatted and written while the caller computes the rest.  The text goes to `<path>.part`; pifu_obj_finish(writer, NULL,
+ * NULL, 0) declares every colour valid, waits, and renames it to `path` (a line whose length was not the predicted one - a NaN
+ * or negative colour - makes it rewrite the file in one pass first); nverts < 0 removes the partial file. */
+int pifu_obj_layout(void *writer, const double *verts, const float *colors, int64_t nverts);
+int pifu_obj_ready(void *writer, int64_t upto);
 int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts);
 
 #ifdef __cplusplus

@@ -74,7 +74,8 @@ SIGNATURES = {
     'pifu_clock_probe': (_i32, [_p, _p, _p]),
     'pifu_write_obj': (_i32, [C.c_char_p, _p, _p, _i64, _p, _i64]),
     'pifu_obj_begin': (_i32, [C.c_char_p, _p, _i64, _i64, _i64, C.POINTER(_p)]),
-    'pifu_obj_vertices': (_i32, [_p, _p, _p, _i64]),
+    'pifu_obj_layout': (_i32, [_p, _p, _p, _i64]),
+    'pifu_obj_ready': (_i32, [_p, _i64]),
     'pifu_obj_finish': (_i32, [_p, _p, _p, _i64]),
 }
 

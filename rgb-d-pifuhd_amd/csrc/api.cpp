@@ -422,6 +422,23 @@ inline char *put_fixed4(char *o, double x)
     return o;
 }
 
+// number of characters put_fixed4 writes for x (same arithmetic, no stores); -1 for values outside its fast range
+inline int fixed4_len(double x)
+{
+    if (!(fabs(x) < 1e11)) return -1;
+    const double ax = fabs(x);
+    const double p = ax * 1e4;
+    const double e = fma(ax, 1e4, -p);
+    const double fl = floor(p);
+    uint64_t n = (uint64_t)fl;
+    const double d = p - fl;
+    if (d > 0.5 || (d == 0.5 && (e > 0.0 || (e == 0.0 && (n & 1))))) ++n;
+    uint64_t ip = n / 10000;
+    int digits = 1;
+    while (ip >= 10) { ip /= 10; ++digits; }
+    return (signbit(x) ? 1 : 0) + digits + 5;
+}
+
 }  // namespace
 
 namespace {
@@ -496,47 +513,86 @@ constexpr size_t OBJ_VERTEX_LINE = 168, OBJ_FACE_LINE = 40;      // upper bounds
 struct ObjWriter {
     int fd = -1;
     std::string path;
-    // vertices handed over in pieces (pifu_obj_vertices) while the caller is still computing the later ones: a queue of
-    // blocks in file order, formatted by a pool that starts with the first piece; a block's file offset is the end of its
-    // predecessor, known as soon as that one is FORMATTED.  The text goes to `path + ".part"`, renamed by pifu_obj_finish.
-    struct VBlock {
-        const double *v; const float *c; int64_t n;
-        std::atomic<int64_t> end{-1};          // file offset behind this block, once it is formatted
-        VBlock(const double *v_, const float *c_, int64_t n_) : v(v_), c(c_), n(n_) {}
-    };
+    // Streaming mode (pifu_obj_layout / pifu_obj_ready), for callers that know every vertex POSITION long before the last
+    // COLOUR (gen_mesh: marching cubes, then the colour loop).  A colour in [0, 10) always prints as 6 characters, so the length
+    // of every vertex line - hence the file offset of every vertex block and of the face section - follows from the positions
+    // alone: the pool measures the blocks as soon as the layout is declared, the face blocks go to their final place while
+    // the caller is still computing colours, and a vertex block is formatted and written the moment its colours are declared
+    // ready.  A block whose text does not have the predicted length (a colour outside [0, 10): NaN, negative) flags a mismatch
+    // and the finish call rewrites the file in one pass from the complete arrays.  The text goes to `path + ".part"`.
+    bool streaming = false;
+    const double *sv = nullptr;
+    const float *sc = nullptr;
+    int64_t sn = 0, svblocks = 0;
+    std::vector<int64_t> vlen, voff;            // predicted bytes per vertex block, their prefix (valid once layout_done)
+    std::vector<int64_t> foff;                  // prefix of the face blocks' bytes (valid once faces_ready)
+    std::atomic<int64_t> measure_next{0}, measured{0}, vnext{0}, ready_upto{0}, faces_formatted{0}, fwrite_next{0};
+    std::atomic<bool> mismatch{false}, vbad{false};
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<VBlock> vblocks;
-    size_t vnext = 0;
-    bool vclosed = false, streaming = false;
+    bool layout_done = false, faces_ready = false, stop = false;      // guarded by mu
     std::vector<std::thread> vpool;
-    std::atomic<bool> vbad{false};
 
-    void format_vertices()
+    int64_t block_lo(int64_t b) const { return b * OBJ_BLOCK; }
+    int64_t block_hi(int64_t b) const { return std::min(sn, (b + 1) * OBJ_BLOCK); }
+
+    void vertex_worker()
     {
+        // (1) measure: predicted text length of every vertex block from the positions alone
+        for (;;) {
+            const int64_t b = measure_next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= svblocks) break;
+            int64_t bytes = 0;
+            bool odd = false;
+            for (int64_t i = block_lo(b); i < block_hi(b); ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const int n = fixed4_len(sv[3 * i + k]);
+                    if (n < 0) odd = true; else bytes += n;
+                }
+            if (odd) mismatch.store(true);                       // a position outside the fast formatter's range: one-pass rewrite
+            vlen[b] = bytes + 26 * (block_hi(b) - block_lo(b));   // 'v' + 6 blanks + 3 x 6 colour characters + newline
+            if (measured.fetch_add(1, std::memory_order_acq_rel) + 1 == svblocks) {
+                for (int64_t q = 0; q < svblocks; ++q) voff[q + 1] = voff[q] + vlen[q];
+                { std::lock_guard<std::mutex> lk(mu); layout_done = true; }
+                cv.notify_all();
+            }
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return layout_done || stop; });
+            if (!layout_done) return;
+        }
+        // (2) format + write the vertex blocks, in order of arrival of their colours
         constexpr size_t FAST = (size_t)OBJ_BLOCK * OBJ_VERTEX_LINE + 64;
         std::unique_ptr<char[]> own(new char[FAST]);               // uninitialised on purpose, re-used per block
-        std::unique_ptr<char[]> big;
         for (;;) {
-            VBlock *b = nullptr, *prev = nullptr;
+            const int64_t b = vnext.fetch_add(1, std::memory_order_relaxed);
+            if (b >= svblocks) break;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return vnext < vblocks.size() || vclosed; });
-                if (vnext >= vblocks.size()) return;
-                b = &vblocks[vnext];
-                prev = vnext ? &vblocks[vnext - 1] : nullptr;     // element addresses of a deque survive push_back
-                ++vnext;
+                cv.wait(lk, [&] { return ready_upto.load() >= block_hi(b) || stop; });
+                if (ready_upto.load() < block_hi(b)) return;     // abandoned
             }
-            const size_t slow = count_slow_values(b->v, b->c, 0, b->n);
-            char *base = own.get();
-            if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
-            char *o = format_vertex_lines(base, b->v, b->c, 0, b->n);
-            int64_t off = 0;
-            if (prev) while ((off = prev->end.load(std::memory_order_acquire)) < 0) std::this_thread::yield();
-            const size_t n = (size_t)(o - base);
-            b->end.store(off + (int64_t)n, std::memory_order_release);
-            if (!write_all(fd, base, n, off)) vbad.store(true);
-            big.reset();
+            if (mismatch.load()) continue;                       // the file is rewritten as a whole anyway
+            if (count_slow_values(sv, sc, block_lo(b), block_hi(b))) { mismatch.store(true); continue; }
+            char *o = format_vertex_lines(own.get(), sv, sc, block_lo(b), block_hi(b));
+            if ((int64_t)(o - own.get()) != vlen[b]) { mismatch.store(true); continue; }
+            if (!write_all(fd, own.get(), (size_t)vlen[b], voff[b])) vbad.store(true);
+        }
+    }
+
+    // the face threads, once every face block is formatted: wait for the vertex layout, then write the blocks in place
+    void write_faces_in_place()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return (layout_done && faces_ready && streaming) || stop; });
+            if (stop) return;
+        }
+        for (;;) {
+            const int64_t b = fwrite_next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks) break;
+            if (!write_all(fd, text[b].get(), len[b], voff[svblocks] + foff[b])) vbad.store(true);
         }
     }
 
@@ -557,7 +613,13 @@ struct ObjWriter {
             text[b].reset(new char[(size_t)(hi - lo) * OBJ_FACE_LINE + 16]);
             char *o = format_face_lines(text[b].get(), faces, row_stride, col_stride, lo, hi);
             len[b] = (size_t)(o - text[b].get());
+            if (faces_formatted.fetch_add(1, std::memory_order_acq_rel) + 1 == nblocks) {
+                for (int64_t q = 0; q < nblocks; ++q) foff[q + 1] = foff[q] + (int64_t)len[q];
+                { std::lock_guard<std::mutex> lk(mu); faces_ready = true; }
+                cv.notify_all();
+            }
         }
+        write_faces_in_place();      // streaming mode only; returns at once when the writer is finished the one-call way
     }
 };
 
@@ -574,6 +636,8 @@ extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nf
     w->nblocks = (nfaces + OBJ_BLOCK - 1) / OBJ_BLOCK;
     w->text.resize((size_t)w->nblocks);
     w->len.assign((size_t)w->nblocks, 0);
+    w->foff.assign((size_t)w->nblocks + 1, 0);
+    if (w->nblocks == 0) w->faces_ready = true;
     // half of the cores: the caller's own work (the colour loop's launches, copies) runs beside these threads
     const int nthreads = w->nblocks ? std::max(1, obj_threads(w->nblocks) / 2) : 0;
     for (int t = 0; t < nthreads; ++t) w->pool.emplace_back([w]() { w->format_faces(); });
@@ -581,23 +645,39 @@ extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nf
     return PIFU_OK;
 }
 
-extern "C" int pifu_obj_vertices(void *writer, const double *verts, const float *colors, int64_t count)
+extern "C" int pifu_obj_layout(void *writer, const double *verts, const float *colors, int64_t nverts)
 {
-    PIFU_REQUIRE(writer && count >= 0 && ((verts && colors) || count == 0), PIFU_ERR_INVALID, "pifu_obj_vertices: bad argument");
+    PIFU_REQUIRE(writer && nverts >= 0 && ((verts && colors) || nverts == 0), PIFU_ERR_INVALID, "pifu_obj_layout: bad argument");
     ObjWriter *w = (ObjWriter *)writer;
-    if (!w->streaming) {
-        const std::string part = w->path + ".part";
-        const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_obj_vertices: cannot open %s", part.c_str());
-        w->fd = fd;
-        w->streaming = true;
-        const int nthreads = std::max(2, obj_threads(1 << 20) / 2);     // beside the face formatters and the caller's launches
-        for (int t = 0; t < nthreads; ++t) w->vpool.emplace_back([w]() { w->format_vertices(); });
-    }
+    PIFU_REQUIRE(!w->streaming, PIFU_ERR_STATE, "pifu_obj_layout: the layout of this writer was already declared");
+    const std::string part = w->path + ".part";
+    const int fd = open(part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    PIFU_REQUIRE(fd >= 0, PIFU_ERR_INVALID, "pifu_obj_layout: cannot open %s", part.c_str());
+    w->fd = fd;
+    w->sv = verts; w->sc = colors; w->sn = nverts;
+    w->svblocks = (nverts + OBJ_BLOCK - 1) / OBJ_BLOCK;
+    w->vlen.assign((size_t)w->svblocks, 0);
+    w->voff.assign((size_t)w->svblocks + 1, 0);
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        for (int64_t lo = 0; lo < count; lo += OBJ_BLOCK)
-            w->vblocks.emplace_back(verts + 3 * lo, colors + 3 * lo, std::min(OBJ_BLOCK, count - lo));
+        w->streaming = true;
+        if (w->svblocks == 0) w->layout_done = true;
+    }
+    const int nthreads = std::max(2, obj_threads(1 << 20) / 2);     // beside the face formatters and the caller's launches
+    for (int t = 0; t < nthreads; ++t) w->vpool.emplace_back([w]() { w->vertex_worker(); });
+    w->cv.notify_all();
+    return PIFU_OK;
+}
+
+extern "C" int pifu_obj_ready(void *writer, int64_t upto)
+{
+    PIFU_REQUIRE(writer, PIFU_ERR_INVALID, "pifu_obj_ready: null writer");
+    ObjWriter *w = (ObjWriter *)writer;
+    PIFU_REQUIRE(w->streaming && upto >= 0 && upto <= w->sn, PIFU_ERR_INVALID, "pifu_obj_ready: %lld vertices declared ready of %lld "
+                 "(declare the layout first)", (long long)upto, (long long)w->sn);
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (upto > w->ready_upto.load()) w->ready_upto.store(upto);
     }
     w->cv.notify_all();
     return PIFU_OK;
@@ -607,44 +687,42 @@ extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *
 {
     PIFU_REQUIRE(writer, PIFU_ERR_INVALID, "pifu_obj_finish: null writer");
     std::unique_ptr<ObjWriter> w((ObjWriter *)writer);
-    if (w->streaming) {                                 // the vertices came through pifu_obj_vertices
+    if (w->streaming) {                                 // layout mode: (NULL, NULL, 0) = every colour is valid now
+        const bool args_ok = nverts < 0 || (nverts == 0 && !verts && !colors);
         {
             std::lock_guard<std::mutex> lk(w->mu);
-            w->vclosed = true;
+            if (nverts >= 0 && args_ok) w->ready_upto.store(w->sn);
+            else w->stop = true;
         }
         w->cv.notify_all();
         for (auto &th : w->vpool) th.join();
         for (auto &th : w->pool) th.join();
         const std::string part = w->path + ".part";
-        const bool args_ok = nverts < 0 || (nverts == 0 && !verts && !colors);
         bool bad = w->vbad.load();
-        if (nverts >= 0 && args_ok && !bad) {
-            const int64_t vbytes = w->vblocks.empty() ? 0 : w->vblocks.back().end.load();
-            // the face blocks were formatted long ago: their offsets are a prefix sum, the writes go out in parallel
-            std::vector<int64_t> off((size_t)w->nblocks + 1, vbytes);
-            for (int64_t b = 0; b < w->nblocks; ++b) off[b + 1] = off[b] + (int64_t)w->len[b];
-            std::atomic<int64_t> next{0};
-            std::atomic<bool> fbad{false};
-            std::vector<std::thread> pool;
-            const int fd = w->fd;
-            ObjWriter *wp = w.get();
-            const int nthreads = w->nblocks ? obj_threads(w->nblocks) : 0;
-            for (int t = 0; t < nthreads; ++t)
-                pool.emplace_back([&, wp, fd]() {
-                    for (;;) {
-                        const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
-                        if (b >= wp->nblocks) break;
-                        if (!write_all(fd, wp->text[b].get(), wp->len[b], off[b])) fbad.store(true);
-                        wp->text[b].reset();
-                    }
-                });
-            for (auto &th : pool) th.join();
-            bad = fbad.load();
+        if (nverts >= 0 && args_ok && !bad && w->mismatch.load()) {
+            // some line did not have the predicted length: one pass over the complete arrays, as the one-call writer does
+            bad = ftruncate(w->fd, 0) != 0;
+            int64_t off = 0;
+            constexpr size_t FAST = (size_t)OBJ_BLOCK * OBJ_VERTEX_LINE + 64;
+            std::unique_ptr<char[]> own(new char[FAST]);
+            for (int64_t b = 0; b < w->svblocks && !bad; ++b) {
+                const size_t slow = count_slow_values(w->sv, w->sc, w->block_lo(b), w->block_hi(b));
+                std::unique_ptr<char[]> big;
+                char *base = own.get();
+                if (slow) { big.reset(new char[FAST + slow * SLOW_CHARS]); base = big.get(); }
+                char *o = format_vertex_lines(base, w->sv, w->sc, w->block_lo(b), w->block_hi(b));
+                if (!write_all(w->fd, base, (size_t)(o - base), off)) bad = true;
+                off += (int64_t)(o - base);
+            }
+            for (int64_t b = 0; b < w->nblocks && !bad; ++b) {
+                if (!write_all(w->fd, w->text[b].get(), w->len[b], off)) bad = true;
+                off += (int64_t)w->len[b];
+            }
         }
         if (close(w->fd) != 0) bad = true;
         if (nverts < 0 || bad || !args_ok) {            // abandoned or failed: the destination is left as it was
             (void)unlink(part.c_str());
-            PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: the vertices of this writer were streamed; finish it "
+            PIFU_REQUIRE(args_ok, PIFU_ERR_INVALID, "pifu_obj_finish: the layout of this writer was declared; finish it "
                          "with (NULL, NULL, 0)");
             PIFU_REQUIRE(nverts < 0, PIFU_ERR_INVALID, "pifu_obj_finish: write error on %s", part.c_str());
             return PIFU_OK;
@@ -652,6 +730,11 @@ extern "C" int pifu_obj_finish(void *writer, const double *verts, const double *
         PIFU_REQUIRE(rename(part.c_str(), w->path.c_str()) == 0, PIFU_ERR_INVALID, "pifu_obj_finish: cannot rename %s", part.c_str());
         return PIFU_OK;
     }
+    {   // one-call form (or an abandoned writer without a layout): the face threads only format, nothing is written in place
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv.notify_all();
     if (nverts < 0) {                                   // abandon: wait for the face formatters, write nothing
         for (auto &th : w->pool) th.join();
         return PIFU_OK;

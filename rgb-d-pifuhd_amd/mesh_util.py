@@ -379,25 +379,30 @@ class ObjFile:
         _lib.call('pifu_obj_begin', str(mesh_path).encode(), f.ctypes.data_as(C.c_void_p), len(f), f.strides[0] // 4,
                   f.strides[1] // 4, C.byref(self._h))
 
-    def add_vertices(self, verts, colors32):
-        """The next vertices of the file (float64 [n,3]) with their colours as the float32 values the reference copies into
-        its float64 colour array; formatted in the background while the caller computes the following ones."""
-        v = np.ascontiguousarray(verts, dtype=np.float64)
-        c = np.ascontiguousarray(colors32, dtype=np.float32)
-        if v.shape != c.shape or v.ndim != 2 or v.shape[1] != 3:
-            raise ValueError('add_vertices: verts and colours must both be [n, 3]')
-        self._keep.append((v, c))                        # read by the worker threads until finish()
-        _lib.call('pifu_obj_vertices', self._h, v.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(v))
+    def layout(self, verts, colors32):
+        """Declare the complete vertex arrays - positions float64 [n,3] (final), colours float32 [n,3] (a buffer the caller
+        still fills in; the float32 values the reference copies into its float64 colour array).  The writer derives every
+        file offset from the positions, puts the face lines in place at once and writes a block of vertex lines as soon
+        as `ready(upto)` has declared its colours valid."""
+        if verts.dtype != np.float64 or colors32.dtype != np.float32 or not verts.flags.c_contiguous or \
+                not colors32.flags.c_contiguous or verts.shape != colors32.shape or verts.ndim != 2 or verts.shape[1] != 3:
+            raise ValueError('layout: verts float64 [n,3] and colours float32 [n,3], both C-contiguous (no copies are made)')
+        self._keep = [verts, colors32]                   # read by the worker threads until finish()
+        _lib.call('pifu_obj_layout', self._h, verts.ctypes.data_as(C.c_void_p), colors32.ctypes.data_as(C.c_void_p), len(verts))
         self._streamed = True
+
+    def ready(self, upto):
+        """The colours of vertices [0, upto) are valid."""
+        _lib.call('pifu_obj_ready', self._h, int(upto))
 
     def finish(self, verts=None, colors=None):
         """Write the file: with the vertices given here (float64 colours, `save_obj_mesh_with_color`'s arguments), or - after
-        `add_vertices` - with the ones already handed over."""
+        `layout` - with the declared arrays, every colour of which is valid by now."""
         h, self._h = self._h, None
         try:
             if self._streamed:
                 if verts is not None or colors is not None:
-                    raise ValueError('finish(): the vertices of this file were already handed over by add_vertices()')
+                    raise ValueError('finish(): the vertices of this file were already declared by layout()')
                 _lib.call('pifu_obj_finish', h, None, None, 0)
             else:
                 v = np.ascontiguousarray(verts, dtype=np.float64)

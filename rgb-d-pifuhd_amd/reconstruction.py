@@ -158,7 +158,8 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
         # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
         # calc_normal calls go to the GPU in a few groups of whole 50 000-vertex calls; each group's colours cross to pinned
-        # host memory on the copy stream as soon as they exist, and the OBJ writer formats that group's vertex lines on its
+        # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
+        # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
         # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
         # asynchronous transfers into pinned buffers beside the colour loop - the extra 200 MB of host copies they need to
         # hand arrays of their own back to the caller cost more than the 15 ms of transfer they hide.)
@@ -190,13 +191,13 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
                 ev.record(side)
             col_d.record_stream(side)
             done.append((l, r, ev))
+        obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
         color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
         for (l, r, ev) in done:
             ev.synchronize()
-            obj.add_vertices(verts[l:r], host_np[l:r])
+            obj.ready(r)                                          # this group's vertex lines are formatted and written now
             color[l:r] = host_np[l:r]                             # while the GPU computes the next group
         t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
-        obj.add_vertices(verts[n_col:], host_np[n_col:])
         obj.finish()
     if png_thread is not None:
         png_thread.join()

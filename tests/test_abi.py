@@ -100,21 +100,46 @@ def test_obj_writer_host_only(lib, tmp_path):
     w = mesh_util.ObjFile(str(p), f[:0])
     w.finish(v[:0], c[:0])
     assert p.read_text() == ''
-    # the three-step form of gen_mesh's colour-loop pipeline: vertices handed over in pieces (any sizes, also empty and larger
-    # than a writer block) with float32 colours - the values the reference copies into its float64 colour array - while
-    # "later" pieces do not exist yet; same bytes as the one-call writer on the float64 copy of those colours
-    c32 = c.astype(np.float32)
-    want = O.obj_text(v, f[:, ::-1], c32.astype(np.float64))
-    w = mesh_util.ObjFile(str(p), f[:, ::-1])
-    cuts = [0, 1, 1, 7, 16384, 16385, 40001, len(v)]
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        w.add_vertices(v[a:b], c32[a:b])
-    assert not p.exists() or p.read_text() != want               # nothing under the final name before finish()
+    # the streaming form of gen_mesh's colour-loop pipeline: positions complete, colours (float32, the values the reference
+    # copies into its float64 colour array) arriving later.  The writer lays the file out from the positions alone - a colour
+    # in [0, 10) is always 6 characters - writes the faces in place at once and the vertex blocks as their colours are
+    # declared ready; same bytes as the one-call writer on the float64 copy of those colours
+    vs = np.ascontiguousarray(v[np.isfinite(v).all(1) & (np.abs(v) < 1e10).all(1)])      # positions inside the fast formatter's range
+    c32 = rs.rand(len(vs), 3).astype(np.float32)
+    c32[::97] = 0.0
+    c32[5::113] = 1.0
+    fs = rs.randint(0, len(vs), size=(70001, 3)).astype(np.int32)
+    want = O.obj_text(vs, fs[:, ::-1], c32.astype(np.float64))
+    late = np.full_like(c32, np.nan)                               # what the buffer holds before the colours arrive
+    w = mesh_util.ObjFile(str(p), fs[:, ::-1])
+    w.layout(vs, late)
+    for upto in (0, 1, 7, 16384, 16385, 40001, len(vs)):
+        late[:upto] = c32[:upto]
+        w.ready(upto)
+    assert p.read_text() != want                                   # nothing under the final name before finish()
     w.finish()
     assert p.read_text() == want and not (tmp_path / 'a.obj.part').exists()
-    # abandoned mid-stream: the previous file stays, the partial one goes
-    w = mesh_util.ObjFile(str(p), f)
-    w.add_vertices(v[:100], c32[:100])
+    # colours that do not print as 6 characters (NaN, negative, >= 10) and positions outside the fast range break the
+    # predicted layout: the finish call notices and rewrites the file in one pass - still the one-call writer's bytes
+    odd = c32.copy()
+    odd[3] = [np.nan, -0.25, 12.5]
+    odd[20000, 1] = -1e-9
+    for verts_, cols_ in ((vs, odd), (v, rs.rand(len(v), 3).astype(np.float32))):
+        ff = rs.randint(0, len(verts_), size=(50000, 3)).astype(np.int32)
+        w = mesh_util.ObjFile(str(p), ff)
+        w.layout(np.ascontiguousarray(verts_), cols_)
+        w.ready(len(verts_) // 2)
+        w.finish()
+        assert p.read_text() == O.obj_text(verts_, ff, cols_.astype(np.float64))
+    # an empty mesh, and a writer abandoned mid-stream: the previous file stays, the partial one goes
+    w = mesh_util.ObjFile(str(p), fs[:0])
+    w.layout(vs[:0], c32[:0])
+    w.finish()
+    assert p.read_text() == ''
+    p.write_text(want)
+    w = mesh_util.ObjFile(str(p), fs)
+    w.layout(vs, c32)
+    w.ready(100)
     del w
     assert p.read_text() == want and not (tmp_path / 'a.obj.part').exists()
     # a writer abandoned between the two steps (an exception in the colour loop) leaves the previous file as it was, and
