@@ -68,10 +68,11 @@ def _upload_beside(t, dev):
     return out
 
 
-def _span_groups(spans, ngroups):
-    """Vertex ranges (left, right) made of whole consecutive spans, `ngroups` of near-equal length (fewer when there are
-    fewer spans): the units of the colour-loop pipeline."""
-    per = max((len(spans) + ngroups - 1) // ngroups, 1)
+def _span_groups(spans, per=10):
+    """Vertex ranges (left, right) made of `per` whole consecutive spans each: the units of the colour-loop pipeline.  Ten
+    50 000-vertex calc_normal calls are 2.0 M point rows: one batch of launches of a 2 M-row workspace, two of the default
+    1 M-row one, in both cases without a small left-over batch."""
+    per = max(int(per), 1)
     return [(spans[i][0], spans[min(i + per, len(spans)) - 1][1]) for i in range(0, len(spans), per)]
 
 
@@ -157,7 +158,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     else:
         # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
         # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
-        # calc_normal calls go to the GPU in a few groups of whole 50 000-vertex calls; each group's colours cross to pinned
+        # calc_normal calls go to the GPU in groups of ten whole 50 000-vertex calls; each group's colours cross to pinned
         # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
         # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
         # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
@@ -182,7 +183,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
         done = []
         # (_pipeline=False - tools/genmesh_ab.py - is the unpipelined form for A/B timing: one group, vertex lines at the end)
-        for (l, r) in _span_groups(spans, 8 if _pipeline else 1):
+        for (l, r) in _span_groups(spans, 10 if _pipeline else len(spans)):
             col_d = normals_of(l, r).contiguous()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
