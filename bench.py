@@ -649,7 +649,7 @@ def main():
                 if mc_ms > 0:
                     ach = mc_bytes / (mc_ms * 1e-3) / 1e9
                     secondary.append({
-                        'kernel': 'marching cubes (k_mc_bricks/minmax/count/scan + k_mc_verts/faces) of the gen_mesh run',
+                        'kernel': 'marching cubes (k_mc_nodebricks / brick_combine / groups / count / scan + k_mc_verts / faces) of the gen_mesh runs, per call',
                         'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(ach / PEAK_HBM_GBS, 4), 'ms': round(mc_ms, 3),
                         'alg_bytes': round(mc_bytes), 'alg_bytes_definition': 'one pass over the float64 SDF (R^3 x 8 B) + 12 B per '
