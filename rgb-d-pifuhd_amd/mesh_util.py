@@ -281,6 +281,14 @@ def to_host(t):
     return arr
 
 
+def pinned_flat(tag, n, dtype):
+    """Flat pinned host buffer of at least `n` elements kept (and grown) across calls, one per tag."""
+    buf = _pinned.get(tag)
+    if buf is None or buf.numel() < n or buf.dtype != dtype:
+        buf = _pinned[tag] = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+    return buf
+
+
 def pinned_rows(tag, n, dtype):
     """[n, 3] view of a pinned host buffer kept (and grown) across calls, one per tag."""
     buf = _pinned.get(tag)

@@ -17,26 +17,40 @@ import torch
 
 from numpy.linalg import inv
 
-from .mesh_util import ObjFile, copy_stream, pinned_rows, reconstruction, save_obj_mesh_with_color
+from .mesh_util import ObjFile, copy_stream, pinned_flat as mesh_util_pinned, pinned_rows, reconstruction, save_obj_mesh_with_color
 from .nets import index
 
 
 def _save_debug_png(path, image_tensor_global, background=False):
-    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`).  With `background=True` the pixel fetch and
-    the PNG encoding (zlib, GIL released) run on a thread that the caller joins before returning."""
+    """Horizontal strip of the [-1,1] images, RGB (`reconstruction.py:36-54`).  With `background=True` the PNG encoding
+    (zlib, GIL released) runs on a thread that the caller joins before returning."""
     try:
         from PIL import Image
     except Exception:          # pragma: no cover - PIL is optional plumbing
         return None
     strip = torch.cat([image_tensor_global[v, :3] for v in range(image_tensor_global.shape[0])], 2)      # [3, H, n*W]
-    arr = (strip.detach().permute(1, 2, 0) * 0.5 + 0.5) * 255.0
-
-    def encode():                                                 # the fetch waits for the encoders only: also off the caller's path
+    arr = ((strip.detach().permute(1, 2, 0) * 0.5 + 0.5) * 255.0).contiguous()
+    if not background or not arr.is_cuda:
         tiles = np.clip(np.rint(arr.cpu().numpy()), 0, 255).astype(np.uint8)
         Image.fromarray(tiles).save(path, compress_level=1)      # cv2.imwrite's default PNG compression level is 1 too
-    if not background:
-        encode()
         return None
+    # The pixels cross on the copy stream into pinned memory (issued here, not waited for), the thread waits for that copy
+    # alone and encodes.  It must not touch the compute stream: a `.cpu()` from the thread synchronises the stream the octree
+    # evaluation is being issued into at that moment and stalls the issuing thread - measured 0 - 35 ms per call.
+    dev = arr.device
+    host = mesh_util_pinned('png', arr.numel(), torch.float32)[:arr.numel()].view(arr.shape)
+    side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        host.copy_(arr, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record(side)
+    arr.record_stream(side)
+
+    def encode():
+        landed.synchronize()
+        tiles = np.clip(np.rint(host.numpy()), 0, 255).astype(np.uint8)
+        Image.fromarray(tiles).save(path, compress_level=1)
     th = threading.Thread(target=encode)
     th.start()
     return th
