@@ -97,6 +97,9 @@ class _Subject:
     def __init__(self, net, data):
         dev = net.device
         self.calib = data['calib'].to(device=dev)
+        # the same matrix on the host, for this package's own calls: they only need its 16 numbers there, and fetching them
+        # from the device copy would synchronise the stream every time (once per calc_normal group in the colour loop)
+        self.calib_host = data['calib'].detach().cpu()
         coarse = data['img_512'].to(device=dev)
         # same two calls as the reference, arranged so that independent work overlaps: the coarse call returns while its
         # hourglass still runs (the fine level does not read it), and the 1024 px image crosses PCIe on a copy stream while
@@ -132,7 +135,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         return time.perf_counter()
     t0 = mark()
     subj = _Subject(net, data)
-    calib_tensor = subj.calib
+    calib_tensor = subj.calib_host
     t1 = mark()
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
