@@ -291,7 +291,8 @@ def main():
             # RCCL's own account of what it built (rings / trees, transport per channel, and - where the build logs it - the
             # algorithm and protocol it picks per collective): written by every rank to its own file, summarised once below
             rccl_log = os.path.join(tempfile.gettempdir(), f'pifu_rccl_{os.getpid()}_r{rank}.log')
-            os.environ.setdefault('NCCL_DEBUG', 'INFO')
+            if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION', 'WARN'):      # the image exports VERSION
+                os.environ['NCCL_DEBUG'] = 'INFO'                                         # (the output goes to the file below)
             os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
             os.environ.setdefault('NCCL_DEBUG_FILE', rccl_log)
             # a rank that dies takes the job down (torch.distributed.run ends its siblings); a rank that hangs is cut by this

@@ -147,6 +147,8 @@ def test_bench_dist_selftest_under_torchrun(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['dist_selftest']['backend'] == 'nccl' and line['n_gpus'] == 1 and line['value'] > 0
+    # what RCCL reported about the communicator it built (NCCL_DEBUG=INFO into a per-rank file, summarised once)
+    assert line['rccl']['lines'] and any('nChannels' in ln or 'Ring' in ln for ln in line['rccl']['lines'])
     assert 'error' not in line['gen_mesh'].get('one_subject_sharded', {'error': 1})
 
 
