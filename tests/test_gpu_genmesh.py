@@ -410,3 +410,28 @@ def test_result_arrays_are_the_callers_own():
     vd, fd = run(128)                                              # everything dropped: the slabs are taken back
     assert {vd.ctypes.data, fd.ctypes.data} & addr
     assert np.array_equal(vd, keep_v) and np.array_equal(fd, keep_f)
+
+
+def test_gen_mesh_is_reproducible_run_to_run(tmp_path):
+    """The marching-cubes surface list is filled in a run-dependent order (one atomic per block) and the OBJ file is written
+    by many host threads at offsets derived ahead of time: neither may show in the results.  Four runs at 128^3 (several
+    counting blocks, several writer blocks): identical arrays and identical file bytes."""
+    import hashlib
+    from pifuhd_amd import nets, reconstruction, synth
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = {'name': 't', 'img': synth.synthetic_image(128, 3, seed=3), 'img_512': synth.synthetic_image(64, 3, seed=2),
+            'calib': calib_tensor(), 'b_min': [-1, -1, -1], 'b_max': [1, 1, 1]}
+    netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
+    seen = set()
+    for k in range(4):
+        p = str(tmp_path / f'r{k}.obj')
+        v, f, c = reconstruction.gen_mesh(128, netMR, 'cuda', data, p)
+        h = hashlib.sha256()
+        for a in (v, f, c):
+            h.update(np.ascontiguousarray(a).tobytes())
+        seen.add((h.hexdigest(), hashlib.sha256(open(p, 'rb').read()).hexdigest()))
+        assert len(v) > 20000
+    assert len(seen) == 1
