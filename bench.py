@@ -822,11 +822,18 @@ def main():
         out['dist_selftest'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                 'collectives': 'all_gather_into_tensor (field, colours), all_reduce(MAX), barrier',
                                 'note': 'functional check of the multi-rank code path on one rank; not a measurement'}
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=_real_stdout if '_real_stdout' in globals() else sys.stdout, flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    # stdout carries the JSON line and nothing else: whatever the package prints on the way (the reference's own messages,
+    # e.g. 'error cannot marching cubes') goes to stderr
+    _real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        main()
+    finally:
+        sys.stdout = _real_stdout

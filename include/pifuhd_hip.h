@@ -70,6 +70,15 @@ enum {
                                               feat_nchw must not be read by anyone else */
 };
 
+/* Version of the contracts in this header; pifu_abi_version() returns the value the library was built with, and a binding
+ * must refuse a library whose value differs (the Python binding does, _lib.load()).
+ *   1: rounds 1-2.
+ *   2: round 3 - pifu_obj_finish in one-call mode creates / truncates `path` (abandon = nverts < 0); open_edge of
+ *      pifu_face_components is a bit mask; the `all_stacks` argument of pifu_filter_coarse became the PIFU_ENC_* flags word.
+ *   3: round 4 - explicit point lists (pifu_query, pifu_calc_normal*) of PIFU_PIXEL_TABLE_MIN_POINTS points or more take the
+ *      coarse level's image-feature products from per-pixel tables (PIFU_Q_NO_COLUMN_SHARING keeps the per-point GEMMs);
+ *      pifu_enc_join semantics: every stream that asks before the deferred hourglass has finished waits for it. */
+#define PIFU_ABI_VERSION 3
 const char *pifu_last_error(void);
 int pifu_abi_version(void);
 
@@ -96,6 +105,16 @@ int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight,
  * 2 = fp16 x 3: the same three products on the fp16 matrix cores with the weight planes scaled by 2^11 (operands good to
  * 2^-22: ~1e-6 on the occupancy; needs |w| < 32 and |activations| < 65504, the first is checked). */
 int pifu_set_precision(pifu_ctx *ctx, int mode);
+/* Pixel tables for explicit point lists (pifu_query, pifu_calc_normal*).  index() is linear in the feature map, so the
+ * products of the coarse MLP's weights with the sampled image features (layer 0 and the skip connections, MLP.py:58-64) are
+ * W * sum_t w_t F[tap_t] = sum_t w_t (W * F[tap_t]): the table G = W * F is computed once per feature map (H * W pixel rows)
+ * and a point blends four rows of it instead of running a K = 256 GEMM per point - 23 % fewer FLOPs on the calc_normal path,
+ * same result up to fp32 summation order (~1e-6 on the occupancy).  mode 0: never; 1 (default): for calls of at least
+ * PIFU_PIXEL_TABLE_MIN_POINTS points; 2: always.  PIFU_Q_NO_COLUMN_SHARING on a call keeps the per-point GEMMs whatever the
+ * mode.  The table (H * W x 1536 floats: 100 MB for the 128^2 map) lives in the context and is rebuilt when the coarse
+ * feature map, the coarse MLP or the precision mode changes. */
+#define PIFU_PIXEL_TABLE_MIN_POINTS 16384
+int pifu_set_pixel_tables(pifu_ctx *ctx, int mode);
 /* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
  * z_div = z_size of the COARSE net's options. */
 int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);

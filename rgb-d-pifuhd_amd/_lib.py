@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libpifuhd_hip.so')
 
+ABI_VERSION = 3          # PIFU_ABI_VERSION of include/pifuhd_hip.h this binding was written against
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
@@ -17,6 +18,8 @@ NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
 PROF_GEMM, PROF_SAMPLER, PROF_MC = 0, 1, 2
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
 ENC_ALL_STACKS, ENC_DEFER_JOIN = 1, 2
+PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables
+PIXEL_TABLE_MIN_POINTS = 16384
 
 
 class PifuError(RuntimeError):
@@ -43,6 +46,7 @@ SIGNATURES = {
     'pifu_mlp_define': (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32]),
     'pifu_mlp_set_layer': (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'pifu_set_precision': (_i32, [_p, _i32]),
+    'pifu_set_pixel_tables': (_i32, [_p, _i32]),
     'pifu_set_depth_normalizer': (_i32, [_p, _f, _f]),
     'pifu_set_features': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
     'pifu_enc_set_param': (_i32, [_p, C.c_char_p, _p, _p, _i32]),
@@ -95,6 +99,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        built = lib.pifu_abi_version()
+        if built != ABI_VERSION:
+            raise PifuError(ERR_STATE, f'{LIB_PATH} was built for ABI version {built}, this binding expects {ABI_VERSION}: '
+                                       f'rebuild it (make -C rgb-d-pifuhd_amd/csrc) - a stale library would misread arguments')
         _lib = lib
     return _lib
 

@@ -30,7 +30,7 @@ void pifu_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *pifu_last_error(void) { return g_err; }
-extern "C" int pifu_abi_version(void) { return 1; }
+extern "C" int pifu_abi_version(void) { return PIFU_ABI_VERSION; }
 
 int pifu_ensure(DevBuf &b, size_t bytes)
 {
@@ -134,7 +134,7 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
         for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(ctx->mlp[L].layer[i]);
         if (ctx->feat[L].nhwc) (void)hipFree(ctx->feat[L].nhwc);
     }
-    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc, &ctx->col_arena, &ctx->sel_counts};
+    DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->misc, &ctx->col_arena, &ctx->pix_arena, &ctx->sel_counts};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int L = 0; L < 2; ++L)
@@ -220,7 +220,8 @@ extern "C" int pifu_reserve(pifu_ctx *ctx, int64_t rows)
 
 extern "C" int64_t pifu_workspace_bytes(pifu_ctx *ctx)
 {
-    return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes) : 0;
+    return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes + ctx->col_arena.bytes +
+                           ctx->pix_arena.bytes) : 0;
 }
 
 // 0 = exact fp32 MFMA (default); 1 = bf16 x 3 split precision (~1e-5 on the occupancy); 2 = fp16 x 3 (~1e-6)
@@ -234,6 +235,15 @@ extern "C" int pifu_set_precision(pifu_ctx *ctx, int mode)
         ctx->bf16_planes.clear();
     }
     ctx->precision = mode;
+    ctx->pix.valid = false;            // the pixel table is a product of the GEMM in the current arithmetic
+    return PIFU_OK;
+}
+
+// pixel tables of explicit point lists: 0 never, 1 from PIFU_PIXEL_TABLE_MIN_POINTS points on (default), 2 always
+extern "C" int pifu_set_pixel_tables(pifu_ctx *ctx, int mode)
+{
+    PIFU_REQUIRE(ctx && mode >= 0 && mode <= 2, PIFU_ERR_INVALID, "pifu_set_pixel_tables: mode must be 0 (off), 1 (auto) or 2 (always)");
+    ctx->pix_mode = mode;
     return PIFU_OK;
 }
 
@@ -258,6 +268,7 @@ extern "C" int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, in
     Mlp &m = ctx->mlp[level];
     for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(m.layer[i]);
     if (m.colW) { (void)hipFree(m.colW); m.colW = nullptr; }
+    if (level == 0) ctx->pix.valid = false;
     m = Mlp();
     m.ndims = ndims;
     m.nlayers = ndims - 1;
@@ -352,7 +363,7 @@ extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const flo
     for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);      // device addresses may be reused by new weights
     ctx->bf16_planes.clear();
     m.col_built = false;
-    if (level == 0) ctx->mlp[1].col_built = false;
+    if (level == 0) { ctx->mlp[1].col_built = false; ctx->pix.valid = false; }
     if (l.has_norm) {
         std::vector<float> g(l.cout_pad, 0.f), be(l.cout_pad, 0.f), fs(l.cout_pad, 0.f), fb(l.cout_pad, 0.f);
         if (m.norm != PIFU_NORM_NONE) {

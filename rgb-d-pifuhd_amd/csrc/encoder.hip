@@ -1274,8 +1274,14 @@ int pifu_enc_join(pifu_ctx *ctx, hipStream_t st)
 {
     auto it = g_states.find(ctx);
     if (it == g_states.end() || !it->second->coarse_pending) return PIFU_OK;
+    // Every stream that asks while the hourglass is still running waits for it - not only the first one: a later query,
+    // set_features or filter call on ANOTHER stream is ordered after the deferred work too.  Once the event has completed
+    // nobody needs to wait any more and the flag is dropped.
+    const hipError_t q = hipEventQuery(it->second->ev_coarse);
+    if (q == hipSuccess) { it->second->coarse_pending = false; return PIFU_OK; }
+    if (q != hipErrorNotReady) PIFU_HIP(q);
+    (void)hipGetLastError();                   // hipErrorNotReady is an answer, not an error to leave behind
     PIFU_HIP(hipStreamWaitEvent(st, it->second->ev_coarse, 0));
-    it->second->coarse_pending = false;
     return PIFU_OK;
 }
 
@@ -1389,6 +1395,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
             fm.bytes = bytes;
         }
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
+        ctx->pix.valid = false;           // the pixel table of the point-list queries belongs to the previous map
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
                                   hipMemcpyDeviceToDevice, S.cur->st));
         if (feat_nchw && all_stacks) {      // train mode (PIFuNetwNML.py:94-97 keeps the whole list): [num_stack][C][H/4][W/4]

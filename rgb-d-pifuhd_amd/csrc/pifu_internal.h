@@ -121,6 +121,10 @@ struct pifu_ctx {
     DevBuf col_arena;
     int col_enable = 1;
     int walk_enable = 1;                  // depth walk of coarse layer 1 on lattice sources
+    // pixel tables of explicit point lists (query.hip "Pixel tables"): G = W_feat * F over the pixels of the coarse map
+    int pix_mode = 1;                     // pifu_set_pixel_tables: 0 off, 1 from PIFU_PIXEL_TABLE_MIN_POINTS points on, 2 always
+    DevBuf pix_arena;
+    struct PixState { bool valid = false; const float *feat = nullptr; int H = 0, W = 0, C = 0, precision = 0, ldg = 0; } pix;
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs

@@ -74,6 +74,7 @@ struct GemmArgs {
     const float *colwz;   // [cout_pad] weight of the depth feature, or null
     const float *zf;      // [rows] depth feature per point row
     const int *colidx;    // [rows] column of the point row
+    int qrel;             // pixel tables: colQ is a per-ROW table [rows][ldq] (row r starts from colQ[r]); colidx is not read
     // per-K-step operand descriptors (k_mlp_gemm_split): everything that depends on the segment is resolved on the
     // host, so the kernel fetches one descriptor per step with scalar loads instead of a ~60-instruction select chain
     struct StepDesc {
@@ -206,7 +207,7 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
 // K step costs one more barrier here (the tile is overwritten in place once every wave has read its fragments), which the
 // two other resident blocks cover.  Same tiles, k order and statistics as k_mlp_gemm_buf: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int PRIO>
+template <int PRIO, int QREL = 0>
 __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 {
     constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
@@ -262,6 +263,21 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
             acc01[r] = fmaf(wz1, zA, 0.f);
             acc10[r] = fmaf(wz0, zB, 0.f);
             acc11[r] = fmaf(wz1, zB, 0.f);
+        }
+    } else if (QREL) {     // pixel tables: the start values of row r are row r of a per-row table (no index to fetch)
+        const __amdgpu_buffer_rsrc_t rZ = buf_rsrc(a.zf + row0);
+        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(a.colQ + row0 * (size_t)a.ldq + a.qoff + col0);
+        const unsigned vrow = (unsigned)(wm * 64 + 4 * h) * 4u, ldq4 = (unsigned)a.ldq * 4u;
+        const unsigned vq = (unsigned)(wm * 64 + 4 * h) * ldq4 + (unsigned)(wn * 64 + j) * 4u;
+        const float wz0 = a.colwz ? a.colwz[col0 + wn * 64 + j] : 0.f, wz1 = a.colwz ? a.colwz[col0 + wn * 64 + 32 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned lr = (unsigned)((r & 3) + 8 * (r >> 2));
+            const float zA = buf_load1(rZ, vrow, lr * 4u), zB = buf_load1(rZ, vrow, lr * 4u + 128u);
+            acc00[r] = fmaf(wz0, zA, buf_load1(rQ, vq, lr * ldq4));
+            acc01[r] = fmaf(wz1, zA, buf_load1(rQ, vq, lr * ldq4 + 128u));
+            acc10[r] = fmaf(wz0, zB, buf_load1(rQ, vq, (lr + 32u) * ldq4));
+            acc11[r] = fmaf(wz1, zB, buf_load1(rQ, vq, (lr + 32u) * ldq4 + 128u));
         }
     } else if (a.colQ) {   // column sharing: accumulators start from Q[col] + wz * z (gathered while the first tile is in flight)
         const __amdgpu_buffer_rsrc_t rI = buf_rsrc(a.colidx + row0), rZ = buf_rsrc(a.zf + row0);
@@ -532,9 +548,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const size_t rowA = row0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh, rowB = rowA + 32;
-            const int ciA = a.colidx[rowA], ciB = a.colidx[rowB];
+            const size_t ciA = a.qrel ? rowA : (size_t)a.colidx[rowA], ciB = a.qrel ? rowB : (size_t)a.colidx[rowB];
             const float zA = a.zf[rowA], zB = a.zf[rowB];
-            const float *qA = a.colQ + (size_t)ciA * a.ldq + a.qoff, *qB = a.colQ + (size_t)ciB * a.ldq + a.qoff;
+            const float *qA = a.colQ + ciA * a.ldq + a.qoff, *qB = a.colQ + ciB * a.ldq + a.qoff;
             acc00[r] = WS * fmaf(wz0, zA, qA[c0]);
             acc01[r] = WS * fmaf(wz1, zA, qA[c1]);
             acc10[r] = WS * fmaf(wz0, zB, qB[c0]);
@@ -713,6 +729,7 @@ struct LastArgs {
     float wz0;
     const float *zf;
     const int *colidx;
+    int qrel;                // pixel tables: colQ is a per-row table, colidx is not read
 };
 
 // LPR lanes per point row: 8 for the usual 128-wide input (four independent 16-byte loads per lane in flight: the kernel
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(256) void k_last_layer(const LastArgs a)
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
     if (sub == 0 && valid) {
-        if (a.colQ) dot += fmaf(a.wz0, a.zf[row], a.colQ[(size_t)a.colidx[row] * a.ldq + a.qoff]);
+        if (a.colQ) dot += fmaf(a.wz0, a.zf[row], a.colQ[(a.qrel ? (size_t)row : (size_t)a.colidx[row]) * a.ldq + a.qoff]);
         float p = 1.f / (1.f + expf(-(dot + a.bias)));
         if (a.mask_bit && !(a.mask[row] & a.mask_bit)) p = 0.f;     // pred * in_bb
         a.out[(int64_t)c * a.g.chunk + local] = p;
@@ -791,6 +808,8 @@ struct SampleArgs {
     float *finef; int ldf;
     uint8_t *mask;
     float *zf;                // per-point sampler: the depth feature once more as a column of its own (or null)
+    int4 *pix_idx;            // pixel tables: the four coarse taps of the row (pixel index, 0 for a tap outside the map) and
+    float4 *pix_wt;           // their weights (0 outside) INSTEAD of the gathered coarse features (featc is not written)
     int64_t rows;
     ChunkGeom g;
 };
@@ -840,9 +859,14 @@ __global__ void k_sample(const SampleArgs a)
     float *fc_out = a.featc + (size_t)row * a.ldc;
     float *ff_out = a.finef ? a.finef + (size_t)row * a.ldf : nullptr;
     if (!valid) {   // padded row: zero features keep every downstream value finite; excluded from statistics
-        for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
+        if (!a.pix_idx)
+            for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
         if (ff_out && lane * 4 < a.ldf) *reinterpret_cast<float4 *>(ff_out + lane * 4) = make_float4(0, 0, 0, 0);
-        if (lane == 0) { a.mask[row] = 0; if (a.zf) a.zf[row] = 0.f; }
+        if (lane == 0) {
+            a.mask[row] = 0;
+            if (a.zf) a.zf[row] = 0.f;
+            if (a.pix_idx) { a.pix_idx[row] = make_int4(0, 0, 0, 0); a.pix_wt[row] = make_float4(0, 0, 0, 0); }
+        }
         return;
     }
     const int64_t i = a.src.first + (int64_t)c * a.g.chunk + local;   // point index within the call
@@ -878,21 +902,28 @@ __global__ void k_sample(const SampleArgs a)
     int off[4];
     float wt[4];
     bilinear_setup(x, y, a.Wc, a.Hc, off, wt);
-    for (int ch = lane * 4; ch < a.Ccp; ch += 256) {
-        float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (off[t] >= 0) {
-                const float4 v = *reinterpret_cast<const float4 *>(a.fc + (size_t)off[t] * a.Ccp + ch);
-                acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
-                acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
-            }
+    if (a.pix_idx) {   // pixel tables: the taps themselves; k_expand_pix blends the rows of G = W_feat * F with them
+        if (lane == 0) {
+            a.pix_idx[row] = make_int4(off[0] < 0 ? 0 : off[0], off[1] < 0 ? 0 : off[1], off[2] < 0 ? 0 : off[2], off[3] < 0 ? 0 : off[3]);
+            a.pix_wt[row] = make_float4(off[0] < 0 ? 0.f : wt[0], off[1] < 0 ? 0.f : wt[1], off[2] < 0 ? 0.f : wt[2], off[3] < 0 ? 0.f : wt[3]);
         }
-        *reinterpret_cast<float4 *>(fc_out + ch) = acc;
+    } else {
+        for (int ch = lane * 4; ch < a.Ccp; ch += 256) {
+            float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (off[t] >= 0) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.fc + (size_t)off[t] * a.Ccp + ch);
+                    acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
+                    acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
+                }
+            }
+            *reinterpret_cast<float4 *>(fc_out + ch) = acc;
+        }
+        // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
+        for (int col = a.Cc + lane; col < a.ldc; col += 64)
+            fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
     }
-    // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
-    for (int col = a.Cc + lane; col < a.ldc; col += 64)
-        fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
     if (a.zf && lane == 0) a.zf[row] = (z * a.z_mul) / a.z_div;
 
     if (ff_out) {
@@ -981,6 +1012,85 @@ __global__ void k_expand(const float *Q, int ldq, const float *wz, const float *
 #pragma unroll
         for (int t = 0; t < 8; ++t) { ss += red[0][t][threadIdx.x]; qq += red[1][t][threadIdx.x]; }
         partial[(size_t)tile_m * ldy + c0 + threadIdx.x] = make_float2(ss, qq);
+    }
+}
+
+// Pixel tables (explicit point lists).  index() is linear in the feature map, so W_feat * index(F, uv) = sum over the four
+// taps of w_t * (W_feat * F[tap_t]): with G = W_feat * F computed once per feature map (one row per pixel), the coarse
+// layer-0 output of a point is a bilinear blend of four rows of G (+ wz * z + bias) and the image-feature part of the
+// skip connections is the same blend of other columns of G - no K = 256 product per point is left.  Blend in tap order
+// (nw, ne, sw, se) by FMA, like k_sample blends the features themselves.
+// One block per (128-row tile, 128 columns): thread = 4 columns x 16 rows.  Column blocks [0, n0) are layer 0 (output Y +
+// statistics partials, like k_expand), the rest are the skip products (raw blend -> S, the per-row start-value table of
+// the later GEMMs).  Consecutive rows with the same four taps (the p / p+dx / p+dy / p+dz rows of a calc_normal vertex,
+// mostly) reuse the rows of G they hold in registers.
+struct PixArgs {
+    const float *G; int ldg;            // [H * W][ldg]
+    int g0, g1;                         // first G column of layer 0 / of the skip blocks
+    const int4 *idx; const float4 *wt;  // per row: taps and weights (k_sample in pixel mode)
+    const float *wz, *bias, *zf;        // layer 0: depth weight, bias; depth feature per row
+    float *Y; int ldy; float2 *partial; // layer-0 output [rows][ldy] + (sum, sum^2) partials per (tile, column), or null
+    int n0;                             // 128-column blocks of layer 0
+    float *S; int lds;                  // skip products [rows][lds]
+    ChunkGeom g;
+};
+
+__global__ __launch_bounds__(256) void k_expand_pix(const PixArgs a)
+{
+    __shared__ float red[2][8][128];
+    const int tile_m = blockIdx.x;
+    const bool l0 = (int)blockIdx.y < a.n0;
+    const int c0 = (l0 ? blockIdx.y : blockIdx.y - a.n0) * 128;
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int ch = c0 + cg * 4;
+    const float *Gc = a.G + (l0 ? a.g0 : a.g1) + ch;
+    const int chunk_id = tile_m / a.g.tpc;
+    const int local0 = (tile_m % a.g.tpc) * BM;
+    int nvalid = chunk_len(a.g, chunk_id) - local0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
+    float4 w = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+    if (l0) { w = *reinterpret_cast<const float4 *>(a.wz + ch); b = *reinterpret_cast<const float4 *>(a.bias + ch); }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    int4 held = make_int4(-1, -1, -1, -1);
+    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+    for (int r = rg * 16; r < rg * 16 + 16; ++r) {
+        const size_t row = (size_t)tile_m * BM + r;
+        const int4 id = a.idx[row];
+        const float4 wt = a.wt[row];
+        if (id.x != held.x || id.y != held.y || id.z != held.z || id.w != held.w) {
+            v0 = *reinterpret_cast<const float4 *>(Gc + (size_t)id.x * a.ldg);
+            v1 = *reinterpret_cast<const float4 *>(Gc + (size_t)id.y * a.ldg);
+            v2 = *reinterpret_cast<const float4 *>(Gc + (size_t)id.z * a.ldg);
+            v3 = *reinterpret_cast<const float4 *>(Gc + (size_t)id.w * a.ldg);
+            held = id;
+        }
+        float4 o;
+        o.x = fmaf(v3.x, wt.w, fmaf(v2.x, wt.z, fmaf(v1.x, wt.y, fmaf(v0.x, wt.x, 0.f))));
+        o.y = fmaf(v3.y, wt.w, fmaf(v2.y, wt.z, fmaf(v1.y, wt.y, fmaf(v0.y, wt.x, 0.f))));
+        o.z = fmaf(v3.z, wt.w, fmaf(v2.z, wt.z, fmaf(v1.z, wt.y, fmaf(v0.z, wt.x, 0.f))));
+        o.w = fmaf(v3.w, wt.w, fmaf(v2.w, wt.z, fmaf(v1.w, wt.y, fmaf(v0.w, wt.x, 0.f))));
+        if (!l0) {
+            *reinterpret_cast<float4 *>(a.S + row * a.lds + ch) = o;
+            continue;
+        }
+        const float z = a.zf[row];
+        o.x = fmaf(w.x, z, o.x) + b.x; o.y = fmaf(w.y, z, o.y) + b.y;
+        o.z = fmaf(w.z, z, o.z) + b.z; o.w = fmaf(w.w, z, o.w) + b.w;
+        *reinterpret_cast<float4 *>(a.Y + row * a.ldy + ch) = o;
+        if (r < nvalid) {
+            s[0] += o.x; q[0] = fmaf(o.x, o.x, q[0]); s[1] += o.y; q[1] = fmaf(o.y, o.y, q[1]);
+            s[2] += o.z; q[2] = fmaf(o.z, o.z, q[2]); s[3] += o.w; q[3] = fmaf(o.w, o.w, q[3]);
+        }
+    }
+    if (!l0 || !a.partial) return;      // block-uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][rg][cg * 4 + k] = s[k]; red[1][rg][cg * 4 + k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { ss += red[0][t][threadIdx.x]; qq += red[1][t][threadIdx.x]; }
+        a.partial[(size_t)tile_m * a.ldy + c0 + threadIdx.x] = make_float2(ss, qq);
     }
 }
 
@@ -1080,11 +1190,15 @@ struct Plan {
     float *coarse_scratch;
     float *zf;        // column sharing: depth feature per row
     int *colidx;      // column sharing: column of the row
+    int4 *pix_idx;    // pixel tables: taps and weights of the row, and the per-row skip products [rows][ldS]
+    float4 *pix_wt;
+    float *S; int ldS;
     LevelBufs lv[2];
     size_t bytes;
 };
 
-Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fine, int64_t normal_pts, bool walk = false)
+Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fine, int64_t normal_pts, bool walk = false,
+           int pix_ldS = -1 /* >= 0: pixel-table mode with that many skip-product columns */)
 {
     Plan p;
     Carver c{base};
@@ -1108,7 +1222,12 @@ Plan carve(pifu_ctx *ctx, char *base, int64_t rows, int64_t max_chunks, bool fin
     }
     const Mlp &mc = ctx->mlp[0];
     p.ldc = (int)round_up(mc.dims[0], BK);
-    p.featc = c.take<float>((size_t)rows * p.ldc);
+    const bool pix = pix_ldS >= 0;
+    p.featc = pix ? nullptr : c.take<float>((size_t)rows * p.ldc);      // pixel tables: the coarse features are never gathered
+    p.pix_idx = pix ? c.take<int4>((size_t)rows) : nullptr;
+    p.pix_wt = pix ? c.take<float4>((size_t)rows) : nullptr;
+    p.ldS = pix ? pix_ldS : 0;
+    p.S = pix && pix_ldS > 0 ? c.take<float>((size_t)rows * pix_ldS) : nullptr;
     p.ldf = fine ? (int)round_up(ctx->feat[1].C > 0 ? ctx->feat[1].C : 16, BK) : 0;
     p.finef = fine ? c.take<float>((size_t)rows * p.ldf) : nullptr;
     p.mask = c.take<uint8_t>((size_t)rows);
@@ -1179,6 +1298,7 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
         f.bytes = bytes;
     }
     f.C = C; f.Cpad = C; f.H = H; f.W = W;
+    if (level == 0) ctx->pix.valid = false;      // the pixel table belongs to the previous map
     dim3 grid((H * W + 31) / 32, (C + 31) / 32);
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, feat_nchw, f.nhwc, C, C, H * W);
     PIFU_HIP(hipGetLastError());
@@ -1199,7 +1319,8 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     if (lab_launch_fp32_gemm(ctx, a, st)) return;
 #endif
     (void)ctx;
-    hipLaunchKernelGGL(k_mlp_gemm_tri<0>, dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 }
 
 static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st);
@@ -1493,8 +1614,57 @@ static int build_column_tables(pifu_ctx *ctx, bool fine, const SampleArgs &proto
     return PIFU_OK;
 }
 
+// Pixel tables (explicit point lists; see k_expand_pix): G[pixel][col_rows] = colW * F[pixel] over the pixels of the coarse
+// map, the same stacked weights as the column tables.  Built on first use after the map, the coarse MLP or the precision
+// mode changed (their setters drop `ctx->pix.valid`); 12.9 GFLOP for the 128^2 x 256 map.
+struct PixMode {
+    const float *G; int ldg;
+    int g1;          // first G column of the skip blocks (= width of layer 0's block)
+    int nS;          // 128-column skip blocks the call needs (those of the layers it runs)
+};
+
+static int build_pixel_table(pifu_ctx *ctx, hipStream_t st)
+{
+    int rc = build_column_weights(ctx, 0);
+    if (rc) return rc;
+    const Mlp &m = ctx->mlp[0];
+    const FeatMap &f = ctx->feat[0];
+    pifu_ctx::PixState &px = ctx->pix;
+    if (px.valid && px.feat == f.nhwc && px.H == f.H && px.W == f.W && px.C == f.C && px.precision == ctx->precision &&
+        px.ldg == m.col_rows)
+        return PIFU_OK;
+    const int64_t hw = (int64_t)f.H * f.W, hw_pad = round_up(hw, BM);
+    const size_t gbytes = ((size_t)hw_pad * m.col_rows * sizeof(float) + 255) & ~(size_t)255;
+    const size_t fbytes = hw != hw_pad ? (size_t)hw_pad * f.Cpad * sizeof(float) : 0;     // row tiles must not read past the map
+    rc = pifu_ensure(ctx->pix_arena, gbytes + fbytes + 256);
+    if (rc) return rc;
+    float *G = (float *)ctx->pix_arena.p;
+    const float *A = f.nhwc;
+    if (fbytes) {
+        float *Fp = (float *)((char *)ctx->pix_arena.p + gbytes);
+        PIFU_HIP(hipMemcpyAsync(Fp, f.nhwc, (size_t)hw * f.Cpad * sizeof(float), hipMemcpyDeviceToDevice, st));
+        PIFU_HIP(hipMemsetAsync(Fp + (size_t)hw * f.Cpad, 0, (size_t)(hw_pad - hw) * f.Cpad * sizeof(float), st));
+        A = Fp;
+    }
+    ChunkGeom g;
+    g.tpc = (int)(hw_pad / BM); g.chunk = (int)hw; g.last_len = (int)hw; g.nchunks = 1;
+    GemmArgs a{};
+    a.seg[0] = Seg{A, ctx->ident_scale, ctx->ident_shift, f.Cpad, m.col_k, 0, 0};
+    a.nseg = 1;
+    a.W = m.colW; a.ldw = m.col_k; a.bias = ctx->ident_shift;      // zeros
+    a.Y = G; a.ldy = m.col_rows; a.partial = nullptr;
+    a.ntm = g.tpc; a.ntn = m.col_rows / BN; a.g = g;
+    double real_rows = 0;
+    for (int i = 0; i < m.nlayers; ++i) if (m.layer[i].cin_feat) real_rows += m.layer[i].cout;
+    rc = run_gemm(ctx, a, 2.0 * hw * real_rows * (double)(m.dims[0] - 1), st);
+    if (rc) return rc;
+    px.valid = true; px.feat = f.nhwc; px.H = f.H; px.W = f.W; px.C = f.C; px.precision = ctx->precision; px.ldg = m.col_rows;
+    return PIFU_OK;
+}
+
 static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTables &T, const ChunkGeom &g, int64_t rows,
-                            int mask_bit, float *pred_out, int upto_layer, hipStream_t st, int walk_nseg = 0)
+                            int mask_bit, float *pred_out, int upto_layer, hipStream_t st, int walk_nseg = 0,
+                            const PixMode *px = nullptr /* coarse level from the pixel tables instead of column tables */)
 {
     const bool walk = L == 0 && walk_nseg > 0;      // coarse layer 1 by the depth walk (walk.inc)
     const Mlp &m = ctx->mlp[L];
@@ -1525,6 +1695,13 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                                    l.cout_pad, l.cout / groups, groups, (const float *)l.gamma, (const float *)l.beta,
                                    b.scale[i], b.shift[i], g, 1e-5f, 1, (const int *)w.chunk_seg0);
                 continue;
+            } else if (ns == 0 && px) {   // coarse layer 0 (+ the skip products of the later layers) blended from the pixel table
+                PixArgs pa{};
+                pa.G = px->G; pa.ldg = px->ldg; pa.g0 = l.col_off > 0 ? l.col_off : 0; pa.g1 = px->g1;
+                pa.idx = pl.pix_idx; pa.wt = pl.pix_wt; pa.wz = l.wz; pa.bias = l.bias; pa.zf = pl.zf;
+                pa.Y = b.out[i]; pa.ldy = l.cout_pad; pa.partial = stats ? b.partial[i] : nullptr;
+                pa.n0 = l.cout_pad / 128; pa.S = pl.S; pa.lds = pl.ldS; pa.g = g;
+                hipLaunchKernelGGL(k_expand_pix, dim3(ntm, pa.n0 + px->nS), dim3(256), 0, st, pa);
             } else if (ns == 0) {   // coarse layer 0: no per-point product left
                 // with the depth walk nobody reads this layer's output: statistics only
                 hipLaunchKernelGGL(k_expand, dim3(ntm, l.cout_pad / 128), dim3(256), 0, st, (const float *)T.Q[L], T.ldq[L],
@@ -1583,7 +1760,10 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 a.Y = b.out[i]; a.ldy = l.cout_pad;
                 a.partial = stats ? b.partial[i] : nullptr;
                 a.ntm = ntm; a.ntn = l.cout_pad / BN; a.g = g;
-                if (l.cin_feat) {
+                if (l.cin_feat && px) {
+                    a.colQ = pl.S; a.ldq = pl.ldS; a.qoff = l.col_off - px->g1; a.qrel = 1; a.colwz = L == 0 ? l.wz : nullptr;
+                    a.zf = pl.zf;
+                } else if (l.cin_feat) {
                     a.colQ = T.Q[L]; a.ldq = T.ldq[L]; a.qoff = l.col_off; a.colwz = L == 0 ? l.wz : nullptr;
                     a.zf = pl.zf; a.colidx = pl.colidx;
                 }
@@ -1604,7 +1784,10 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
             a.w = l.w_col; a.bias = l.host_bias0; a.mask = pl.mask; a.mask_bit = mask_bit; a.out = pred_out; a.rows = rows; a.g = g;
-            if (l.cin_feat) {
+            if (l.cin_feat && px) {
+                a.colQ = pl.S; a.ldq = pl.ldS; a.qoff = l.col_off - px->g1; a.qrel = 1; a.wz0 = L == 0 ? l.host_wz0 : 0.f;
+                a.zf = pl.zf;
+            } else if (l.cin_feat) {
                 a.colQ = T.Q[L]; a.ldq = T.ldq[L]; a.qoff = l.col_off; a.wz0 = L == 0 ? l.host_wz0 : 0.f;
                 a.zf = pl.zf; a.colidx = pl.colidx;
             }
@@ -1676,10 +1859,31 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                   (N1 == 256 || N1 == 512 || N1 == 1024) && res[2] < 65536 && (mc.merge_layer >= 1 || !fine) &&
                   rows_cap * 4 < ((int64_t)1 << 31);
     }
-    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok);
-    int rc = pifu_ensure(ctx->arena, probe.bytes);
+    // pixel tables (explicit point lists): the coarse level's image-feature products blended from G = W_feat * F
+    const bool want_coarse = pred_coarse != nullptr || (flags & PIFU_Q_FULL_COARSE);
+    const int upto_c = want_coarse ? mc.nlayers : mc.merge_layer + 1;
+    bool pixmode = !colmode && (src_mode == 0 || src_mode == 3) && !(flags & PIFU_Q_NO_COLUMN_SHARING) && ctx->pix_mode != 0 &&
+                   (ctx->pix_mode == 2 || n >= PIFU_PIXEL_TABLE_MIN_POINTS) && mc.nlayers >= 2 && !mc.res[0] &&
+                   ctx->feat[0].C % BK == 0 && ctx->feat[0].Cpad == ctx->feat[0].C;
+#ifdef PIFU_LAB     // the lab kernels (tools/lab) do not know GemmArgs::qrel
+    pixmode = false;
+#endif
+    PixMode pxm{};
+    int rc = PIFU_OK;
+    if (pixmode) {
+        rc = build_pixel_table(ctx, st);
+        if (rc != PIFU_OK) return rc;
+        pxm.G = (const float *)ctx->pix_arena.p; pxm.ldg = ctx->pix.ldg;
+        pxm.g1 = (int)round_up(mc.layer[0].cout, BN);
+        int hi = pxm.g1;
+        for (int i = 1; i < upto_c; ++i)
+            if (mc.layer[i].cin_feat) hi = mc.layer[i].col_off + (int)round_up(mc.layer[i].cout, BN);
+        pxm.nS = (hi - pxm.g1) / BN;
+    }
+    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
+    rc = pifu_ensure(ctx->arena, probe.bytes);
     if (rc != PIFU_OK) return rc;
-    Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts, walk_ok);
+    Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
 
     float *fine_out = pred_fine;
     if (src_mode == 3) {   // calc_normal consumes the predictions itself
@@ -1773,14 +1977,17 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             rc = pifu_prof_begin(ctx, PIFU_PROF_SAMPLER, st, &es);
             if (rc != PIFU_OK) return rc;
             sa.zf = pl.zf;
+            sa.pix_idx = pl.pix_idx; sa.pix_wt = pl.pix_wt;      // pixel tables: taps instead of gathered coarse features
             hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
             // algorithmic bytes of the per-point sampler: 4 bilinear taps x (coarse + fine channels) gathered, one MLP
-            // input row (coarse + fine) written, per valid point
-            const double per_point = 4.0 * (sa.Ccp + (fine ? sa.Cfp : 0)) * 4.0 + (double)(pl.ldc + pl.ldf) * 4.0;
+            // input row (coarse + fine) written, per valid point (pixel tables: fine channels + 32 B of taps only)
+            const double per_point = pixmode ? 4.0 * (fine ? sa.Cfp : 0) * 4.0 + (double)pl.ldf * 4.0 + 32.0
+                                             : 4.0 * (sa.Ccp + (fine ? sa.Cfp : 0)) * 4.0 + (double)(pl.ldc + pl.ldf) * 4.0;
             rc = pifu_prof_end(ctx, PIFU_PROF_SAMPLER, es, per_point * (double)npts, st);
             if (rc != PIFU_OK) return rc;
         }
-        rc = launch_level(ctx, 0, pl, g, rows, pl.mask, 1, coarse_dst, upto, st);
+        if (pixmode) rc = launch_level_col(ctx, 0, pl, T, g, rows, 1, coarse_dst, upto, st, 0, &pxm);
+        else rc = launch_level(ctx, 0, pl, g, rows, pl.mask, 1, coarse_dst, upto, st);
         if (rc != PIFU_OK) return rc;
         if (phi && total_chunks == 1) {
             const MlpLayer &lm = mc.layer[mc.merge_layer];

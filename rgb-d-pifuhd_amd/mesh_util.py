@@ -8,6 +8,8 @@ HIP kernels.  Everything computes through the C ABI in `include/pifuhd_hip.h`.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import torch
@@ -209,29 +211,34 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     else:
         sdf, _ = eval_grid_device(net, calib_tensor, resolution, num_samples, use_octree)
     try:
+        # only what the reference's own try block can fail on - the level outside the volume's range (ValueError) or no
+        # surface (RuntimeError), mesh_util.py:84,94-96 - is turned into the printed -1; anything else (an allocation, a
+        # failed copy) surfaces as the error it is
         if sharded and pdist.collective_active() and int(resolution) >= pdist.SLAB_MC_MIN_RESOLUTION:
             verts_d, faces_d = pdist.marching_cubes_sharded(ctx, sdf, thresh)
         else:
             verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
-        faces = to_host(faces_d)
-        _, calib_inv = calib_pair(calib_tensor)
-        mat = np.eye(4)
-        mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
-        mat[0:3, 3] = -1.0
-        trans_mat = np.matmul(calib_inv, mat)
-        verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)                       # mesh_util.py:87-89
-        if np.linalg.det(trans_mat[:3, :3]) < 0.0:
-            faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
-        normals = np.zeros((0, 3), np.float32)
-        values = np.zeros((0,), np.float32)
-        if return_sdf:
-            return verts, faces, normals, values, sdf
-        if return_device_verts:
-            return verts, faces, normals, values, verts_dev
-        return verts, faces, normals, values
+    except _lib.PifuError:               # (a RuntimeError too: a failed HIP call is not "no surface")
+        raise
     except (ValueError, RuntimeError):
         print('error cannot marching cubes')                                             # mesh_util.py:94-96
         return -1
+    faces = to_host(faces_d)
+    _, calib_inv = calib_pair(calib_tensor)
+    mat = np.eye(4)
+    mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
+    mat[0:3, 3] = -1.0
+    trans_mat = np.matmul(calib_inv, mat)
+    verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)                       # mesh_util.py:87-89
+    if np.linalg.det(trans_mat[:3, :3]) < 0.0:
+        faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
+    normals = np.zeros((0, 3), np.float32)
+    values = np.zeros((0,), np.float32)
+    if return_sdf:
+        return verts, faces, normals, values, sdf
+    if return_device_verts:
+        return verts, faces, normals, values, verts_dev
+    return verts, faces, normals, values
 
 
 _pinned = {}
@@ -248,31 +255,53 @@ def copy_stream(dev):
 
 
 _slabs = []          # [pinned uint8 tensor, weak reference to the array last handed out from it]
-POOL_RESULTS = True  # False: plain `.cpu().numpy()` results (tools/genmesh_ab.py times the difference)
+POOL_RESULTS = os.environ.get('PIFU_POOL_RESULTS', '1') != '0'      # False: plain `.cpu().numpy()` results
+POOL_MAX_BYTES = int(os.environ.get('PIFU_POOL_MAX_BYTES', str(1 << 30)))      # page-locked bytes the result pool may hold
+POOL_MAX_SLABS = 6
+
+
+def _pool_bytes():
+    return sum(s[0].numel() for s in _slabs)
+
+
+def _drop_slab(slab):
+    # by identity: list.remove() would compare the entries, i.e. the tensors, element by element
+    _slabs[:] = [s for s in _slabs if s is not slab]
 
 
 def to_host(t):
     """Device tensor -> host array OF THE CALLER'S OWN, without a fresh pageable allocation per call (a 100 MB result costs
     ~25 000 page faults plus a staged copy each time): the copy lands in a pinned slab, and the returned array is a view of
     it.  A slab is handed out again only once the array it backed is gone - arrays and every view of them are tracked
-    through a weak reference, since numpy views keep their parent alive - so a caller that keeps a result keeps its memory;
-    when all slabs are in use (or the tensor is small) this is the plain `.cpu().numpy()`."""
+    through a weak reference, since numpy views keep their parent alive - so a caller that keeps a result keeps its memory
+    (a raw address taken from the array, `arr.ctypes.data`, is NOT tracked: keep the array).  When all slabs are in use,
+    when the pool would exceed POOL_MAX_BYTES (default 1 GiB, env PIFU_POOL_MAX_BYTES) or when the tensor is small this is
+    the plain `.cpu().numpy()`.  A free slab more than 4x the size of the request is released instead of reused, so one
+    1024^3 mesh does not pin its footprint for the life of the process; `release_pinned()` drops everything that is free,
+    and PIFU_POOL_RESULTS=0 switches the pool off."""
     import weakref
     t = t.contiguous()
     nbytes = t.numel() * t.element_size()
     if nbytes < (4 << 20) or not POOL_RESULTS:
         return t.cpu().numpy()
+    want = nbytes + nbytes // 4
     slot = None
-    for s in _slabs:
-        if s[1]() is None:
-            if s[0].numel() < nbytes:
-                s[0] = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=True)      # free but too small: regrow
+    for s in list(_slabs):
+        if s[1]() is not None:
+            continue
+        if s[0].numel() > 4 * want:                   # free and far too large: give the pages back
+            _drop_slab(s)
+            continue
+        if s[0].numel() >= nbytes:
             slot = s
             break
     if slot is None:
-        if len(_slabs) >= 6:
+        for s in list(_slabs):                         # a free slab that is too small makes room for one that fits
+            if s[1]() is None and _pool_bytes() + want > POOL_MAX_BYTES:
+                _drop_slab(s)
+        if len(_slabs) >= POOL_MAX_SLABS or _pool_bytes() + want > POOL_MAX_BYTES:
             return t.cpu().numpy()
-        slot = [torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, pin_memory=True), lambda: None]
+        slot = [torch.empty(want, dtype=torch.uint8, pin_memory=True), lambda: None]
         _slabs.append(slot)
     view = slot[0][:nbytes].view(t.dtype).view(t.shape)
     view.copy_(t)
@@ -281,20 +310,44 @@ def to_host(t):
     return arr
 
 
-def pinned_flat(tag, n, dtype):
-    """Flat pinned host buffer of at least `n` elements kept (and grown) across calls, one per tag."""
-    buf = _pinned.get(tag)
+def _pin_key(tag, dev):
+    """Scratch buffers belong to one (tag, device, host thread): two devices, or two threads calling gen_mesh at the same
+    time, never share one."""
+    dev = torch.device(dev) if dev is not None else None
+    return (tag, None if dev is None else dev.index, threading.get_ident())
+
+
+def pinned_flat(tag, n, dtype, dev=None):
+    """Flat pinned host buffer of at least `n` elements kept (and grown) across calls, one per (tag, device, thread)."""
+    key = _pin_key(tag, dev)
+    buf = _pinned.get(key)
     if buf is None or buf.numel() < n or buf.dtype != dtype:
-        buf = _pinned[tag] = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+        buf = _pinned[key] = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
     return buf
 
 
-def pinned_rows(tag, n, dtype):
-    """[n, 3] view of a pinned host buffer kept (and grown) across calls, one per tag."""
-    buf = _pinned.get(tag)
+def pinned_rows(tag, n, dtype, dev=None):
+    """[n, 3] view of a pinned host buffer kept (and grown) across calls, one per (tag, device, thread)."""
+    key = _pin_key(tag, dev)
+    buf = _pinned.get(key)
     if buf is None or buf.shape[0] < n or buf.dtype != dtype:
-        buf = _pinned[tag] = torch.empty(max(n, 1), 3, dtype=dtype, pin_memory=True)
+        buf = _pinned[key] = torch.empty(max(n, 1), 3, dtype=dtype, pin_memory=True)
     return buf[:n]
+
+
+def release_pinned():
+    """Give back the page-locked host memory this module holds: every result slab whose array is gone and every scratch
+    buffer (`pinned_flat` / `pinned_rows`).  Call it between subjects of very different size, or when the process moves on
+    to other work.  Returns the number of bytes released.  Not to be called while a gen_mesh of this process is running."""
+    freed = 0
+    for s in list(_slabs):
+        if s[1]() is None:
+            freed += s[0].numel()
+            _drop_slab(s)
+    for key in list(_pinned):
+        freed += _pinned[key].numel() * _pinned[key].element_size()
+        del _pinned[key]
+    return freed
 
 
 # ------------------------------------------------------------------------------------------------

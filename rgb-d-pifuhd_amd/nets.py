@@ -278,6 +278,10 @@ class PIFuNetwNML(BasePIFuNet):
         images = images.to(self.device, torch.float32).contiguous()
         if images.dim() != 4 or images.shape[0] != 1:
             raise NotImplementedError('images [1,C,H,W] (batch size 1, the reconstruction path)')
+        # with _defer the hourglass still reads `images` on a stream of the library after this method returned; torch's
+        # allocator does not know that stream, so a converted temporary must not go back to it before the join: the net holds
+        # the tensor until the next filter() call replaces it
+        self._coarse_in = images
         o = self.opt
         _, cimg, h, w = images.shape
         if o.hg_down != 'ave_pool':

@@ -38,7 +38,7 @@ def _save_debug_png(path, image_tensor_global, background=False):
     # alone and encodes.  It must not touch the compute stream: a `.cpu()` from the thread synchronises the stream the octree
     # evaluation is being issued into at that moment and stalls the issuing thread - measured 0 - 35 ms per call.
     dev = arr.device
-    host = mesh_util_pinned('png', arr.numel(), torch.float32)[:arr.numel()].view(arr.shape)
+    host = mesh_util_pinned('png', arr.numel(), torch.float32, dev)[:arr.numel()].view(arr.shape)
     side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
@@ -140,85 +140,90 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
 
-    def spans_check(spans):      # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
-        return any(r == l for (l, r) in spans)
+    # from here on the PNG thread reads a pinned buffer of this (device, thread): whatever happens below - reconstruction()
+    # returning -1 (TypeError, like the reference), an empty calc_normal slice, a failed collective - the thread is joined
+    # before gen_mesh is left, so the next subject of a recon() loop cannot overwrite pixels that are still being encoded
+    try:
+        def spans_check(spans):      # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+            return any(r == l for (l, r) in spans)
 
-    # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
-    # (`reconstruction.py:58-70`), several of them per kernel launch
-    def normals_of(left, right):
-        net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=50000)
-        return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
+        # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
+        # (`reconstruction.py:58-70`), several of them per kernel launch
+        def normals_of(left, right):
+            net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=50000)
+            return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
 
-    if exchange:
-        # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
-        # like the reference (reconstruction.py:56)
-        verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
-                                                       use_octree=use_octree, num_samples=5000, sharded=True,
-                                                       return_device_verts=True)
-        t3 = mark()
-        obj = ObjFile(save_path, faces) if rank == 0 else None   # the face lines are formatted while the colours are computed
-        verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
-        spans = _normal_spans(len(verts))
-        if spans_check(spans):
-            # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
-            raise RuntimeError('calc_normal on an empty vertex slice')
-        i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
-        mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
-        runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
-                (pdist.shard_range(len(spans), ws, rk)[:2] for rk in range(ws)) if j1 > j0]
-        color32 = pdist.gather_runs(runs, mine, normals_of, 3, dev)
-        color = np.zeros(verts.shape)
-        color[:color32.shape[0]] = color32.cpu().numpy()
-        t4 = mark()
-        if obj is not None:
-            obj.finish(verts, color)                              # save_obj_mesh_with_color (mesh_util.py:189-198)
-    else:
-        # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
-        # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
-        # calc_normal calls go to the GPU in groups of ten whole 50 000-vertex calls; each group's colours cross to pinned
-        # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
-        # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
-        # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
-        # asynchronous transfers into pinned buffers beside the colour loop - the extra 200 MB of host copies they need to
-        # hand arrays of their own back to the caller cost more than the 15 ms of transfer they hide.)
-        # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
-        # reference (reconstruction.py:56)
-        verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
-                                                       use_octree=use_octree, num_samples=5000, sharded=sharded,
-                                                       return_device_verts=True)
-        t3 = mark()
-        obj = ObjFile(save_path, faces)                           # the face lines are formatted while the colours are computed
-        n_verts = len(verts)
-        spans = _normal_spans(n_verts)
-        if spans_check(spans):
-            raise RuntimeError('calc_normal on an empty vertex slice')
-        verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
-        n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
-        host_col = pinned_rows('colours', n_verts, torch.float32)
-        host_col[n_col:].zero_()
-        host_np = host_col.numpy()
-        side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
-        done = []
-        # (_pipeline=False - tools/genmesh_ab.py - is the unpipelined form for A/B timing: one group, vertex lines at the end)
-        for (l, r) in _span_groups(spans, 10 if _pipeline else len(spans)):
-            col_d = normals_of(l, r).contiguous()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                host_col[l:r].copy_(col_d, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            col_d.record_stream(side)
-            done.append((l, r, ev))
-        obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
-        color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
-        for (l, r, ev) in done:
-            ev.synchronize()
-            obj.ready(r)                                          # this group's vertex lines are formatted and written now
-            color[l:r] = host_np[l:r]                             # while the GPU computes the next group
-        t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
-        obj.finish()
-    if png_thread is not None:
-        png_thread.join()
+        if exchange:
+            # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
+            # like the reference (reconstruction.py:56)
+            verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
+                                                           use_octree=use_octree, num_samples=5000, sharded=True,
+                                                           return_device_verts=True)
+            t3 = mark()
+            obj = ObjFile(save_path, faces) if rank == 0 else None   # the face lines are formatted while the colours are computed
+            verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
+            spans = _normal_spans(len(verts))
+            if spans_check(spans):
+                # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+                raise RuntimeError('calc_normal on an empty vertex slice')
+            i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
+            mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
+            runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
+                    (pdist.shard_range(len(spans), ws, rk)[:2] for rk in range(ws)) if j1 > j0]
+            color32 = pdist.gather_runs(runs, mine, normals_of, 3, dev)
+            color = np.zeros(verts.shape)
+            color[:color32.shape[0]] = color32.cpu().numpy()
+            t4 = mark()
+            if obj is not None:
+                obj.finish(verts, color)                              # save_obj_mesh_with_color (mesh_util.py:189-198)
+        else:
+            # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
+            # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
+            # calc_normal calls go to the GPU in groups of ten whole 50 000-vertex calls; each group's colours cross to pinned
+            # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
+            # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
+            # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
+            # asynchronous transfers into pinned buffers beside the colour loop - the extra 200 MB of host copies they need to
+            # hand arrays of their own back to the caller cost more than the 15 ms of transfer they hide.)
+            # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
+            # reference (reconstruction.py:56)
+            verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
+                                                           use_octree=use_octree, num_samples=5000, sharded=sharded,
+                                                           return_device_verts=True)
+            t3 = mark()
+            obj = ObjFile(save_path, faces)                           # the face lines are formatted while the colours are computed
+            n_verts = len(verts)
+            spans = _normal_spans(n_verts)
+            if spans_check(spans):
+                raise RuntimeError('calc_normal on an empty vertex slice')
+            verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
+            n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
+            host_col = pinned_rows('colours', n_verts, torch.float32, dev)
+            host_col[n_col:].zero_()
+            host_np = host_col.numpy()
+            side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
+            done = []
+            # (_pipeline=False - tools/genmesh_ab.py - is the unpipelined form for A/B timing: one group, vertex lines at the end)
+            for (l, r) in _span_groups(spans, 10 if _pipeline else len(spans)):
+                col_d = normals_of(l, r).contiguous()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    host_col[l:r].copy_(col_d, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                col_d.record_stream(side)
+                done.append((l, r, ev))
+            obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
+            color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
+            for (l, r, ev) in done:
+                ev.synchronize()
+                obj.ready(r)                                          # this group's vertex lines are formatted and written now
+                color[l:r] = host_np[l:r]                             # while the GPU computes the next group
+            t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
+            obj.finish()
+    finally:
+        if png_thread is not None:
+            png_thread.join()
     t5 = time.perf_counter()
     if timings is not None:
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in the header but not exported'
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert handle.pifu_abi_version() == 1
+    assert handle.pifu_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_library_exports_exactly_the_header(lib):

@@ -220,3 +220,40 @@ def test_overlapped_encoder_schedule_is_bit_identical():
     netG.filter(data['img_512'], _defer=True)
     netG.query(pts, calib)
     assert torch.equal(netG.im_feat_list[0], want[2])
+
+
+def test_deferred_hourglass_is_joined_by_every_stream():
+    """`pifu_filter_coarse(PIFU_ENC_DEFER_JOIN)` leaves the hourglass running on a stream of the library.  Every stream that
+    asks for its result while it is still running must wait for it - not only the first one (`pifu_enc_join`): a query
+    issued on a second stream right after another stream made the first call, with no synchronisation in between, sees the
+    finished map; a call that converts its input (float64 host image -> float32 device copy, a temporary of `filter()`)
+    stays correct because the net holds the converted tensor until the next filter call."""
+    from pifuhd_amd import config, nets, synth
+    from helpers import seeded_points
+    oc = config.coarse_opt(); of = config.fine_opt(oc)
+    of.loadSizeBig = 256
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    img = synth.synthetic_image(128, 3, seed=2)
+    pts = seeded_points(5, 3000)
+    calib = synth.synthetic_inputs(512, 3)['calib']
+    netG.filter(img)
+    netG.query(pts, calib)
+    torch.cuda.synchronize()
+    want_feat, want_pred = netG.im_feat_list[0].clone(), netG.get_preds().clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    fine_map = torch.randn(1, 16, 64, 64)
+    for _ in range(3):
+        netG.filter(img.double(), _defer=True)              # the converted copy is a temporary of filter()
+        held = netG._coarse_in
+        assert held.dtype == torch.float32 and held.is_cuda
+        junk = [torch.full_like(held, float('nan')) for _ in range(4)]      # would recycle a freed input block
+        with torch.cuda.stream(s1):                          # a first caller on one stream (it does not touch the coarse map) ...
+            netMR.set_features(fine_map)
+        with torch.cuda.stream(s2):                          # ... and the query on ANOTHER stream, which nobody ordered after
+            netG.query(pts, calib)                           # the hourglass: it has to wait for it as well
+            pred = netG.get_preds()
+        torch.cuda.synchronize()
+        del junk
+        assert torch.equal(netG.im_feat_list[0], want_feat)
+        assert torch.equal(pred, want_pred)

@@ -435,3 +435,60 @@ def test_gen_mesh_is_reproducible_run_to_run(tmp_path):
         seen.add((h.hexdigest(), hashlib.sha256(open(p, 'rb').read()).hexdigest()))
         assert len(v) > 20000
     assert len(seen) == 1
+
+
+def test_result_pool_is_bounded_and_can_be_released():
+    """The pinned result pool (`mesh_util.to_host`) keeps at most POOL_MAX_BYTES page-locked, gives back a free slab that is
+    far larger than what is asked for, and `release_pinned()` returns everything that is not referenced any more."""
+    import gc
+    from pifuhd_amd import mesh_util
+    mesh_util.release_pinned()
+    saved = mesh_util.POOL_MAX_BYTES
+    try:
+        big = torch.arange(48 << 20, dtype=torch.uint8, device='cuda')               # 48 MiB
+        a, a2, a3 = mesh_util.to_host(big), mesh_util.to_host(big[:40 << 20]), mesh_util.to_host(big[:44 << 20])
+        assert np.array_equal(a[:1000], np.arange(1000, dtype=np.uint8)) and mesh_util._pool_bytes() >= (132 << 20)
+        assert len(mesh_util._slabs) == 3
+        del a, a2, a3
+        gc.collect()
+        small = torch.arange(5 << 20, dtype=torch.uint8, device='cuda')              # 5 MiB: the free 50-60 MiB slabs are > 4x that
+        b = mesh_util.to_host(small)
+        assert mesh_util._pool_bytes() < (16 << 20) and len(mesh_util._slabs) == 1
+        mesh_util.POOL_MAX_BYTES = mesh_util._pool_bytes() + (1 << 20)
+        c = mesh_util.to_host(big)                                                    # over the cap: a plain pageable copy
+        assert mesh_util._pool_bytes() < (16 << 20) and np.array_equal(c[-3:], big[-3:].cpu().numpy())
+        held = mesh_util._pool_bytes()
+        assert mesh_util.release_pinned() == 0 or mesh_util._pool_bytes() == held     # b is still referenced: its slab stays
+        assert np.array_equal(b[:7], np.arange(7, dtype=np.uint8))
+        del b, c
+        gc.collect()
+        assert mesh_util.release_pinned() >= held and mesh_util._pool_bytes() == 0
+    finally:
+        mesh_util.POOL_MAX_BYTES = saved
+
+
+def test_gen_mesh_failure_leaves_no_png_thread_behind(tmp_path):
+    """gen_mesh starts the PNG encoder on a thread that reads a pinned buffer of this (device, thread).  When the call fails
+    after that - here marching cubes finds no surface, reconstruction() returns -1 and the tuple-unpack raises TypeError like
+    the reference (`reconstruction.py:56`) - the thread must have been joined before the exception leaves gen_mesh, so the
+    next subject cannot overwrite pixels that are still being encoded; scratch buffers are per (tag, device, thread)."""
+    import threading
+    from pifuhd_amd import mesh_util, nets, reconstruction, synth
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = 128
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = {'name': 't', 'img': synth.synthetic_image(128, 3, seed=3), 'img_512': synth.synthetic_image(64, 3, seed=2),
+            'calib': calib_tensor(), 'b_min': [-1, -1, -1], 'b_max': [1, 1, 1]}
+    before = set(threading.enumerate())
+    for k in range(2):
+        path = str(tmp_path / f'fail{k}.obj')
+        with pytest.raises(TypeError):
+            reconstruction.gen_mesh(48, netMR, 'cuda', data, path)        # octree grid below init_resolution: no surface
+        assert not [t for t in threading.enumerate() if t not in before and t.is_alive()]
+        assert os.path.getsize(path[:-4] + '.png') > 0 and not os.path.exists(path)
+    keys = [k for k in mesh_util._pinned if k[0] == 'png']
+    assert keys and all(k[1] == torch.device('cuda', torch.cuda.current_device()).index and k[2] == threading.get_ident() for k in keys)
+    other = {}
+    th = threading.Thread(target=lambda: other.update(buf=mesh_util.pinned_flat('png', 16, torch.float32, 'cuda:0')))
+    th.start(); th.join()
+    assert all(other['buf'].data_ptr() != mesh_util._pinned[k].data_ptr() for k in keys)

@@ -371,6 +371,17 @@ def test_calc_normal_values_at_the_gen_mesh_batch_size(golden_dir):
     # the chunked entry point on the same vertices is the same single batch
     netMR.calc_normal_chunked(pts[:, None], calib[:, None], calib, interval=n)
     assert torch.equal(netMR.nmls[0].cpu(), torch.from_numpy(nm))
+    # the run above took the pixel tables (200 000 points >= PIFU_PIXEL_TABLE_MIN_POINTS); the per-point GEMM path on the
+    # same batch meets the same goldens and differs from it by fp32 summation order only
+    from pifuhd_amd import _lib
+    _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_OFF)
+    try:
+        netMR.calc_normal(pts[:, None], calib[:, None], calib, keep_pred=True)
+    finally:
+        _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_AUTO)
+    canon = netMR.nml_preds.reshape(-1).cpu().numpy()
+    assert np.abs(canon - want).max() < TOL
+    assert not np.array_equal(canon, pred4) and np.abs(canon - pred4).max() < 2e-5
 
 
 @pytest.mark.parametrize('tag', ['scale_shift', 'rot_y'])
@@ -443,3 +454,110 @@ def test_full_pifu_supervised_forward_all_stacks(golden_dir):
     netG.eval()
     netMR.filter_global(synth.synthetic_image(64, 3, seed=2))
     assert len(netG.im_feat_list) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# Pixel tables (explicit point lists): the coarse level's image-feature products blended from G = W_feat * F
+# (`pifu_set_pixel_tables`; default: calls of >= 16 384 points, i.e. the calc_normal batches of gen_mesh)
+# ------------------------------------------------------------------------------------------------
+def _pixel_tables(net, mode):
+    from pifuhd_amd import _lib
+    _lib.call('pifu_set_pixel_tables', net._ctx.h, mode)
+
+
+@pytest.mark.parametrize('tag,mlp_norm', [('group', 'group'), ('batch', 'batch'), ('none', 'no')])
+def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
+    """The goldens of `test_query_matches_reference_golden` (the imported reference's query / phi / coarse-only outputs, points
+    up to 1.15 outside the box: zero-padded taps and both in-box masks) with the pixel tables forced on at these small
+    sizes, and the distance to the per-point GEMM path on the same points."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build(mlp_norm)
+    calib = calib_tensor()
+    scale = 1.0 if mlp_norm == 'group' else 3.0
+    pts = seeded_points(3, 700)
+    netMR.query(pts, calib)
+    canon = netMR.get_preds()[0, 0].cpu().numpy().copy(), netG.preds[0, 0].cpu().numpy().copy(), netG.phi[0].cpu().numpy().copy()
+    _pixel_tables(netMR, _lib.PIX_ALWAYS)
+    try:
+        netMR.query(pts, calib)
+        fine, coarse, phi = netMR.get_preds()[0, 0].cpu().numpy(), netG.preds[0, 0].cpu().numpy(), netG.phi[0].cpu().numpy()
+        assert np.abs(fine - gold[f'{tag}_a_fine']).max() < TOL * scale
+        assert np.abs(coarse - gold[f'{tag}_a_coarse']).max() < TOL * scale
+        assert np.abs(phi[::16] - gold[f'{tag}_a_phi_sub']).max() < 2e-3 * scale
+        assert np.array_equal(fine == 0, gold[f'{tag}_a_fine'] == 0)
+        assert np.array_equal(coarse == 0, gold[f'{tag}_a_coarse'] == 0)
+        assert not np.array_equal(fine, canon[0])                 # the other path did run
+        assert np.abs(fine - canon[0]).max() < 2e-5 * scale and np.abs(coarse - canon[1]).max() < 2e-5 * scale
+        assert np.abs(phi - canon[2]).max() < 2e-4 * scale
+        pts = seeded_points(4, 1200, lim=1.0)
+        out = []
+        for s in range(0, 1200, 500):
+            netMR.query(pts[:, :, s:s + 500], calib)
+            out.append(netMR.get_preds()[0, 0].cpu().numpy())
+        assert np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max() < TOL * scale
+        netG.query(seeded_points(5, 300), calib)                   # coarse-only net
+        assert np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max() < TOL * scale
+    finally:
+        _pixel_tables(netMR, _lib.PIX_AUTO)
+
+
+def test_pixel_tables_follow_the_feature_map_and_the_flags():
+    """The table belongs to one feature map: a new map (also one whose pixel count is not a multiple of the 128-row GEMM
+    tile: 20 x 20) is picked up by the next call; PIFU_Q_NO_COLUMN_SHARING on a call keeps the per-point GEMMs whatever the
+    mode; mode 1 switches at PIFU_PIXEL_TABLE_MIN_POINTS points."""
+    import ctypes as C
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netG, netMR, *_ = _build()
+    cal = np.ascontiguousarray(calib_tensor()[0].numpy())
+
+    def run(pts, flags, chunk=5000):
+        n = pts.shape[2]
+        out = torch.empty(n, device='cuda')
+        _lib.call('pifu_query', netMR._ctx.h, _ptr(pts), n, cal.ctypes.data_as(C.c_void_p), chunk, flags, _ptr(out), None, None,
+                  _stream_ptr(netMR.device))
+        return out.cpu().numpy()
+    pts = seeded_points(21, 3000, lim=1.05).cuda().contiguous()
+    try:
+        for seed, hc in ((7, 32), (8, 20), (9, 32)):
+            fc, ff = seeded_features(seed, hc=hc)
+            netG.set_features(fc)
+            netMR.set_features(ff)
+            _pixel_tables(netMR, _lib.PIX_OFF)
+            canon = run(pts, 0)
+            _pixel_tables(netMR, _lib.PIX_ALWAYS)
+            pix = run(pts, 0)
+            assert not np.array_equal(pix, canon), hc
+            assert np.abs(pix - canon).max() < 2e-5, hc
+            assert np.array_equal(pix == 0, canon == 0)
+            assert np.array_equal(run(pts, _lib.Q_NO_COLUMN_SHARING), canon)          # the flag wins over the mode
+        _pixel_tables(netMR, _lib.PIX_AUTO)
+        assert np.array_equal(run(pts, 0), canon)                                      # 3 000 points: below the threshold
+        big = seeded_points(22, _lib.PIXEL_TABLE_MIN_POINTS, lim=1.0).cuda().contiguous()
+        auto = run(big, 0)
+        _pixel_tables(netMR, _lib.PIX_OFF)
+        off = run(big, 0)
+        assert not np.array_equal(auto, off) and np.abs(auto - off).max() < 2e-5
+    finally:
+        _pixel_tables(netMR, _lib.PIX_AUTO)
+
+
+def test_calc_normal_with_pixel_tables():
+    """calc_normal's [p, p+dx, p+dy, p+dz] rows through the pixel tables against the per-point GEMM path: the 4n
+    occupancies by value, the normals by angle (forward differences over 1e-3 amplify fp32 rounding ~1e3 x)."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build()
+    calib = calib_tensor()
+    pts = seeded_points(6, 3000, lim=0.9)
+    netMR.calc_normal(pts[:, None], calib[:, None], calib, keep_pred=True)
+    p0, n0 = netMR.nml_preds.reshape(-1).cpu().numpy().copy(), netMR.nmls[0].cpu().numpy().copy()
+    _pixel_tables(netMR, _lib.PIX_ALWAYS)
+    try:
+        netMR.calc_normal(pts[:, None], calib[:, None], calib, keep_pred=True)
+        p1, n1 = netMR.nml_preds.reshape(-1).cpu().numpy(), netMR.nmls[0].cpu().numpy()
+    finally:
+        _pixel_tables(netMR, _lib.PIX_AUTO)
+    assert not np.array_equal(p0, p1)
+    assert np.abs(p0 - p1).max() < 2e-5
+    cos = (n0 * n1).sum(0)
+    assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.9
