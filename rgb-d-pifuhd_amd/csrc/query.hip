@@ -683,11 +683,27 @@ __global__ void k_norm_finalize(const float2 *partial, int ld, int cpg, int grou
     const int ntile = chunk_row0 ? chunk_row0[c + 1] - chunk_row0[c] : ((len + BM - 1) / BM) * halves;
     double s = 0.0, q = 0.0;
     const int total = ntile * cpg;       // (`halves` partial rows per 128-row tile: 2 for k_mlp_gemm_ws)
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int t = i / cpg, ch = grp * cpg + i % cpg;
-        const float2 p = partial[(size_t)(prow0 + t) * ld + ch];
-        s += (double)p.x;
-        q += (double)p.y;
+    {
+        // four independent loads in flight per thread (a 200 000-point chunk has 50 000 partials per group, and the grid is
+        // only chunks x groups blocks: one dependent load per iteration left the kernel waiting on latency), still a fixed order
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        const float2 *base = partial + (size_t)prow0 * ld + grp * cpg;
+        int i = threadIdx.x;
+        for (; i + 768 < total; i += 1024) {
+            const float2 p0 = base[(size_t)(i / cpg) * ld + i % cpg];
+            const float2 p1 = base[(size_t)((i + 256) / cpg) * ld + (i + 256) % cpg];
+            const float2 p2 = base[(size_t)((i + 512) / cpg) * ld + (i + 512) % cpg];
+            const float2 p3 = base[(size_t)((i + 768) / cpg) * ld + (i + 768) % cpg];
+            s += (double)p0.x; q += (double)p0.y; s1 += (double)p1.x; q1 += (double)p1.y;
+            s2 += (double)p2.x; q2 += (double)p2.y; s3 += (double)p3.x; q3 += (double)p3.y;
+        }
+        for (; i < total; i += 256) {
+            const float2 p = base[(size_t)(i / cpg) * ld + i % cpg];
+            s += (double)p.x;
+            q += (double)p.y;
+        }
+        s = (s + s1) + (s2 + s3);
+        q = (q + q1) + (q2 + q3);
     }
     shs[threadIdx.x] = s;
     shq[threadIdx.x] = q;
@@ -848,27 +864,13 @@ __device__ __forceinline__ void bilinear_setup(float u, float v, int W, int H, i
     }
 }
 
-__global__ void k_sample(const SampleArgs a)
+// The point of row `row` of the batch (explicit list, calc_normal quad member, lattice point) projected by orthogonal():
+// false for the padding rows of a chunk.
+__device__ __forceinline__ bool projected_point(const SampleArgs &a, int64_t row, float &x, float &y, float &z)
 {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (row >= a.rows) return;
     const int P = a.g.tpc * BM;
     const int c = (int)(row / P), local = (int)(row % P);
-    const bool valid = local < chunk_len(a.g, c);
-    float *fc_out = a.featc + (size_t)row * a.ldc;
-    float *ff_out = a.finef ? a.finef + (size_t)row * a.ldf : nullptr;
-    if (!valid) {   // padded row: zero features keep every downstream value finite; excluded from statistics
-        if (!a.pix_idx)
-            for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
-        if (ff_out && lane * 4 < a.ldf) *reinterpret_cast<float4 *>(ff_out + lane * 4) = make_float4(0, 0, 0, 0);
-        if (lane == 0) {
-            a.mask[row] = 0;
-            if (a.zf) a.zf[row] = 0.f;
-            if (a.pix_idx) { a.pix_idx[row] = make_int4(0, 0, 0, 0); a.pix_wt[row] = make_float4(0, 0, 0, 0); }
-        }
-        return;
-    }
+    if (local >= chunk_len(a.g, c)) return false;
     const int64_t i = a.src.first + (int64_t)c * a.g.chunk + local;   // point index within the call
     float px, py, pz;
     if (a.src.mode == 0) {
@@ -894,7 +896,25 @@ __global__ void k_sample(const SampleArgs a)
         pz = (float)lattice_dot(gx, gy, gz, m + 8);
     }
     const float *k = a.calib;      // orthogonal(): xyz = R p + t (BasePIFuNet.py:25-43)
-    const float x = ortho_row(k, px, py, pz), y = ortho_row(k + 4, px, py, pz), z = ortho_row(k + 8, px, py, pz);
+    x = ortho_row(k, px, py, pz); y = ortho_row(k + 4, px, py, pz); z = ortho_row(k + 8, px, py, pz);
+    return true;
+}
+
+__global__ void k_sample(const SampleArgs a)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= a.rows) return;
+    float x, y, z;
+    const bool valid = projected_point(a, row, x, y, z);
+    float *fc_out = a.featc + (size_t)row * a.ldc;
+    float *ff_out = a.finef ? a.finef + (size_t)row * a.ldf : nullptr;
+    if (!valid) {   // padded row: zero features keep every downstream value finite; excluded from statistics
+        for (int k = lane * 4; k < a.ldc; k += 256) *reinterpret_cast<float4 *>(fc_out + k) = make_float4(0, 0, 0, 0);
+        if (ff_out && lane * 4 < a.ldf) *reinterpret_cast<float4 *>(ff_out + lane * 4) = make_float4(0, 0, 0, 0);
+        if (lane == 0) { a.mask[row] = 0; if (a.zf) a.zf[row] = 0.f; }
+        return;
+    }
     const bool in_xy = x >= -1.f && x <= 1.f && y >= -1.f && y <= 1.f;
     const bool in_xyz = in_xy && z >= -1.f && z <= 1.f;
     if (lane == 0) a.mask[row] = (uint8_t)((in_xyz ? 1 : 0) | (in_xy ? 2 : 0));
@@ -902,28 +922,21 @@ __global__ void k_sample(const SampleArgs a)
     int off[4];
     float wt[4];
     bilinear_setup(x, y, a.Wc, a.Hc, off, wt);
-    if (a.pix_idx) {   // pixel tables: the taps themselves; k_expand_pix blends the rows of G = W_feat * F with them
-        if (lane == 0) {
-            a.pix_idx[row] = make_int4(off[0] < 0 ? 0 : off[0], off[1] < 0 ? 0 : off[1], off[2] < 0 ? 0 : off[2], off[3] < 0 ? 0 : off[3]);
-            a.pix_wt[row] = make_float4(off[0] < 0 ? 0.f : wt[0], off[1] < 0 ? 0.f : wt[1], off[2] < 0 ? 0.f : wt[2], off[3] < 0 ? 0.f : wt[3]);
-        }
-    } else {
-        for (int ch = lane * 4; ch < a.Ccp; ch += 256) {
-            float4 acc = make_float4(0, 0, 0, 0);
+    for (int ch = lane * 4; ch < a.Ccp; ch += 256) {
+        float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (off[t] >= 0) {
-                    const float4 v = *reinterpret_cast<const float4 *>(a.fc + (size_t)off[t] * a.Ccp + ch);
-                    acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
-                    acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
-                }
+        for (int t = 0; t < 4; ++t) {
+            if (off[t] >= 0) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.fc + (size_t)off[t] * a.Ccp + ch);
+                acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
+                acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
             }
-            *reinterpret_cast<float4 *>(fc_out + ch) = acc;
         }
-        // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
-        for (int col = a.Cc + lane; col < a.ldc; col += 64)
-            fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
+        *reinterpret_cast<float4 *>(fc_out + ch) = acc;
     }
+    // [.. image features (Cc) | z feature | zero pad]; Ccp == Cc is required (Cc % 4 == 0)
+    for (int col = a.Cc + lane; col < a.ldc; col += 64)
+        fc_out[col] = col == a.Cc ? (z * a.z_mul) / a.z_div : 0.f;
     if (a.zf && lane == 0) a.zf[row] = (z * a.z_mul) / a.z_div;
 
     if (ff_out) {
@@ -942,6 +955,49 @@ __global__ void k_sample(const SampleArgs a)
             }
             *reinterpret_cast<float4 *>(ff_out + ch) = acc;
         }
+    }
+}
+
+// Pixel tables: what k_sample leaves for a row, without the coarse gather - the four coarse taps (pixel index, weight; index
+// 0 and weight 0 for a tap outside the map) for k_expand_pix, the depth feature, the in-box masks and the sampled fine
+// features.  The coarse features are never read, so a wave per row would idle: four lanes per row, each gathering a
+// quarter of the fine channels.  Same arithmetic as k_sample, value for value.
+__global__ __launch_bounds__(256) void k_sample_pix(const SampleArgs a)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int sub = threadIdx.x & 3;
+    if (row >= a.rows) return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    const bool valid = projected_point(a, row, x, y, z);
+    float *ff_out = a.finef ? a.finef + (size_t)row * a.ldf : nullptr;
+    int off[4];
+    float wt[4];
+    if (sub == 0) {
+        const bool in_xy = valid && x >= -1.f && x <= 1.f && y >= -1.f && y <= 1.f;
+        const bool in_xyz = in_xy && z >= -1.f && z <= 1.f;
+        a.mask[row] = (uint8_t)((in_xyz ? 1 : 0) | (in_xy ? 2 : 0));
+        a.zf[row] = valid ? (z * a.z_mul) / a.z_div : 0.f;
+        bilinear_setup(x, y, a.Wc, a.Hc, off, wt);
+        a.pix_idx[row] = valid ? make_int4(off[0] < 0 ? 0 : off[0], off[1] < 0 ? 0 : off[1], off[2] < 0 ? 0 : off[2], off[3] < 0 ? 0 : off[3])
+                               : make_int4(0, 0, 0, 0);
+        a.pix_wt[row] = valid ? make_float4(off[0] < 0 ? 0.f : wt[0], off[1] < 0 ? 0.f : wt[1], off[2] < 0 ? 0.f : wt[2], off[3] < 0 ? 0.f : wt[3])
+                              : make_float4(0, 0, 0, 0);
+    }
+    if (!ff_out) return;
+    bilinear_setup(x, y, a.Wf, a.Hf, off, wt);
+    for (int ch = sub * 4; ch < a.ldf; ch += 16) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        if (valid && ch < a.Cfp) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (off[t] >= 0) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.ff + (size_t)off[t] * a.Cfp + ch);
+                    acc.x = fmaf(v.x, wt[t], acc.x); acc.y = fmaf(v.y, wt[t], acc.y);
+                    acc.z = fmaf(v.z, wt[t], acc.z); acc.w = fmaf(v.w, wt[t], acc.w);
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(ff_out + ch) = acc;
     }
 }
 
@@ -1024,6 +1080,13 @@ __global__ void k_expand(const float *Q, int ldq, const float *wz, const float *
 // statistics partials, like k_expand), the rest are the skip products (raw blend -> S, the per-row start-value table of
 // the later GEMMs).  Consecutive rows with the same four taps (the p / p+dx / p+dy / p+dz rows of a calc_normal vertex,
 // mostly) reuse the rows of G they hold in registers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float *p, const float4 &v)
+{
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p));
+}
+
 struct PixArgs {
     const float *G; int ldg;            // [H * W][ldg]
     int g0, g1;                         // first G column of layer 0 / of the skip blocks
@@ -1069,14 +1132,14 @@ __global__ __launch_bounds__(256) void k_expand_pix(const PixArgs a)
         o.y = fmaf(v3.y, wt.w, fmaf(v2.y, wt.z, fmaf(v1.y, wt.y, fmaf(v0.y, wt.x, 0.f))));
         o.z = fmaf(v3.z, wt.w, fmaf(v2.z, wt.z, fmaf(v1.z, wt.y, fmaf(v0.z, wt.x, 0.f))));
         o.w = fmaf(v3.w, wt.w, fmaf(v2.w, wt.z, fmaf(v1.w, wt.y, fmaf(v0.w, wt.x, 0.f))));
-        if (!l0) {
-            *reinterpret_cast<float4 *>(a.S + row * a.lds + ch) = o;
+        if (!l0) {       // streamed outputs (GBs per launch, next read by another kernel): keep them out of the caches G lives in
+            nt_store4(a.S + row * a.lds + ch, o);
             continue;
         }
         const float z = a.zf[row];
         o.x = fmaf(w.x, z, o.x) + b.x; o.y = fmaf(w.y, z, o.y) + b.y;
         o.z = fmaf(w.z, z, o.z) + b.z; o.w = fmaf(w.w, z, o.w) + b.w;
-        *reinterpret_cast<float4 *>(a.Y + row * a.ldy + ch) = o;
+        nt_store4(a.Y + row * a.ldy + ch, o);
         if (r < nvalid) {
             s[0] += o.x; q[0] = fmaf(o.x, o.x, q[0]); s[1] += o.y; q[1] = fmaf(o.y, o.y, q[1]);
             s[2] += o.z; q[2] = fmaf(o.z, o.z, q[2]); s[3] += o.w; q[3] = fmaf(o.w, o.w, q[3]);
@@ -1978,7 +2041,8 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             if (rc != PIFU_OK) return rc;
             sa.zf = pl.zf;
             sa.pix_idx = pl.pix_idx; sa.pix_wt = pl.pix_wt;      // pixel tables: taps instead of gathered coarse features
-            hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
+            if (pixmode) hipLaunchKernelGGL(k_sample_pix, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, sa);
+            else hipLaunchKernelGGL(k_sample, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sa);
             // algorithmic bytes of the per-point sampler: 4 bilinear taps x (coarse + fine channels) gathered, one MLP
             // input row (coarse + fine) written, per valid point (pixel tables: fine channels + 32 B of taps only)
             const double per_point = pixmode ? 4.0 * (fine ? sa.Cfp : 0) * 4.0 + (double)pl.ldf * 4.0 + 32.0
