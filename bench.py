@@ -500,6 +500,48 @@ def main():
         finally:
             _lib.call('pifu_profile_enable', h, 0)
 
+    # ---- the colour loop's kernel path on its own: calc_normal on seeded vertices in gen_mesh's 50 000-vertex calls (each one
+    # GroupNorm batch of 200 000 point rows), through the pixel tables (default for calls of this size) and through the
+    # per-point GEMMs (pifu_set_pixel_tables(ctx, 0): every FLOP of a lean query executed), alternating
+    if world == 1 and not args.no_canonical:
+        try:
+            nv = 500000
+            gv = torch.Generator().manual_seed(5)
+            verts = ((torch.rand(3, nv, generator=gv) * 2 - 1) * 0.9).to(dev).contiguous()
+            cal32 = np.ascontiguousarray(calib[0].numpy().astype(np.float32))
+            nm_out = torch.empty(3, nv, device=dev)
+            pred4 = {m: torch.empty(4 * nv, device=dev) for m in (_lib.PIX_AUTO, _lib.PIX_OFF)}
+
+            def normals_pass(mode):
+                _lib.call('pifu_set_pixel_tables', h, mode)
+                fence()
+                reset_prof(_lib, h)
+                _lib.call('pifu_profile_enable', h, 1)
+                n0 = time.perf_counter()
+                _lib.call('pifu_calc_normal_chunked', h, C.c_void_p(verts.data_ptr()), nv, 50000, cal32.ctypes.data_as(C.c_void_p),
+                          0.001, C.c_void_p(nm_out.data_ptr()), C.c_void_p(pred4[mode].data_ptr()), _stream_ptr(dev))
+                fence()
+                dt = time.perf_counter() - n0
+                _lib.call('pifu_profile_enable', h, 0)
+                ms, _, fl = read_prof(_lib, h, _lib.PROF_GEMM)
+                return dt, ms, fl
+            res_n = {}
+            for mode, key in ((_lib.PIX_AUTO, 'pixel_tables'), (_lib.PIX_OFF, 'per_point_gemms')):
+                normals_pass(mode)
+                runs = sorted(normals_pass(mode) for _ in range(3))
+                dt, ms, fl = runs[1]
+                res_n[key] = {'value': round(4 * nv / dt / 1e6, 2), 'unit': 'Mqueries/s', 'ms': round(dt * 1e3, 2),
+                              'gemm_flop_per_query_executed': round(fl / (4 * nv)),
+                              'gemm_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None}
+            out['calc_normal'] = {'vertices': nv, 'queries': 4 * nv, 'call_size': 50000, **res_n,
+                                  'max_abs_diff_between_paths': float((pred4[_lib.PIX_AUTO] - pred4[_lib.PIX_OFF]).abs().max().item())}
+            log(f"calc_normal: {res_n['pixel_tables']['value']} Mq/s through the pixel tables, {res_n['per_point_gemms']['value']} per point")
+        except Exception as e:
+            out['calc_normal'] = {'error': repr(e)}
+        finally:
+            _lib.call('pifu_profile_enable', h, 0)
+            _lib.call('pifu_set_pixel_tables', h, _lib.PIX_AUTO)
+
     # ---- the same lattice without the coarse MLP's tail (layers 3-4 + sigmoid produce netG.preds, which nothing on the
     # gen_mesh path reads: reconstruction() runs this way); reported beside the headline, never as `value`
     if world == 1 and not args.lean and not args.no_lean_pass:

@@ -105,7 +105,8 @@ int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight,
  * 2 = fp16 x 3: the same three products on the fp16 matrix cores with the weight planes scaled by 2^11 (operands good to
  * 2^-22: ~1e-6 on the occupancy; needs |w| < 32 and |activations| < 65504, the first is checked). */
 int pifu_set_precision(pifu_ctx *ctx, int mode);
-/* Pixel tables for explicit point lists (pifu_query, pifu_calc_normal*).  index() is linear in the feature map, so the
+/* Pixel tables for explicit point lists (pifu_query, pifu_calc_normal*) and for lattice sources whose calibration rules out
+ * column sharing (x or y depends on k).  index() is linear in the feature map, so the
  * products of the coarse MLP's weights with the sampled image features (layer 0 and the skip connections, MLP.py:58-64) are
  * W * sum_t w_t F[tap_t] = sum_t w_t (W * F[tap_t]): the table G = W * F is computed once per feature map (H * W pixel rows)
  * and a point blends four rows of it instead of running a K = 256 GEMM per point - 23 % fewer FLOPs on the calc_normal path,

@@ -420,7 +420,7 @@ __global__ void k_split_planes(const float *W, void *hi_, void *lo_, size_t n, i
     lo[i] = (T)(x - (float)h);
 }
 
-template <int F16>
+template <int F16, int QREL = 0>      // QREL: GemmArgs::qrel as a compile-time constant (a run-time select re-shaped the whole kernel: -10 %)
 __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
 {
     typedef typename SplitT<F16>::T T;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_gemm_split(const GemmArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const size_t rowA = row0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh, rowB = rowA + 32;
-            const size_t ciA = a.qrel ? rowA : (size_t)a.colidx[rowA], ciB = a.qrel ? rowB : (size_t)a.colidx[rowB];
+            const size_t ciA = QREL ? rowA : (size_t)a.colidx[rowA], ciB = QREL ? rowB : (size_t)a.colidx[rowB];
             const float zA = a.zf[rowA], zB = a.zf[rowB];
             const float *qA = a.colQ + ciA * a.ldq + a.qoff, *qB = a.colQ + ciB * a.ldq + a.qoff;
             acc00[r] = WS * fmaf(wz0, zA, qA[c0]);
@@ -1616,8 +1616,10 @@ static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st)
         hipEvent_t e1b;
         rc = pifu_prof_begin(ctx, PIFU_PROF_GEMM, st, &e1b);
         if (rc) return rc;
-        if (ctx->precision == 2) hipLaunchKernelGGL(k_mlp_gemm_split<1>, dim3(nblocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_mlp_gemm_split<0>, dim3(nblocks), dim3(256), 0, st, a);
+        if (ctx->precision == 2 && a.qrel) hipLaunchKernelGGL((k_mlp_gemm_split<1, 1>), dim3(nblocks), dim3(256), 0, st, a);
+        else if (ctx->precision == 2) hipLaunchKernelGGL((k_mlp_gemm_split<1, 0>), dim3(nblocks), dim3(256), 0, st, a);
+        else if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_split<0, 1>), dim3(nblocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_mlp_gemm_split<0, 0>), dim3(nblocks), dim3(256), 0, st, a);
         return pifu_prof_end(ctx, PIFU_PROF_GEMM, e1b, flops, st);
     }
     hipEvent_t e1;
@@ -1925,7 +1927,8 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     // pixel tables (explicit point lists): the coarse level's image-feature products blended from G = W_feat * F
     const bool want_coarse = pred_coarse != nullptr || (flags & PIFU_Q_FULL_COARSE);
     const int upto_c = want_coarse ? mc.nlayers : mc.merge_layer + 1;
-    bool pixmode = !colmode && (src_mode == 0 || src_mode == 3) && !(flags & PIFU_Q_NO_COLUMN_SHARING) && ctx->pix_mode != 0 &&
+    // (also lattice sources whose calibration rules out column sharing: x or y depends on k)
+    bool pixmode = !colmode && !(flags & PIFU_Q_NO_COLUMN_SHARING) && ctx->pix_mode != 0 &&
                    (ctx->pix_mode == 2 || n >= PIFU_PIXEL_TABLE_MIN_POINTS) && mc.nlayers >= 2 && !mc.res[0] &&
                    ctx->feat[0].C % BK == 0 && ctx->feat[0].Cpad == ctx->feat[0].C;
 #ifdef PIFU_LAB     // the lab kernels (tools/lab) do not know GemmArgs::qrel

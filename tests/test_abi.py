@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in the header but not exported'
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert handle.pifu_abi_version() == _lib.ABI_VERSION == 3
+    assert handle.pifu_abi_version() == lib.ABI_VERSION == 3
 
 
 def test_library_exports_exactly_the_header(lib):
@@ -52,6 +52,20 @@ def test_no_cpu_fallback(lib):
         nets.PIFuNetwNML(config.coarse_opt(), 'orthogonal', 'cuda')
     with pytest.raises(lib.PifuError):
         nets.PIFuNetwNML(config.coarse_opt(), 'orthogonal', 'cpu')
+
+
+def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
+    """`_lib.load()` compares `pifu_abi_version()` with the version the binding was written against: a stale or newer
+    library (argument meanings changed between versions, see the header) is refused instead of misread."""
+    lib.load()
+    header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
+    assert int(re.search(r'#define\s+PIFU_ABI_VERSION\s+(\d+)', header).group(1)) == lib.ABI_VERSION
+    monkeypatch.setattr(lib, '_lib', None)
+    monkeypatch.setattr(lib, 'ABI_VERSION', lib.ABI_VERSION + 1)
+    with pytest.raises(lib.PifuError, match='ABI version'):
+        lib.load()
+    monkeypatch.undo()
+    assert lib.load().pifu_abi_version() == lib.ABI_VERSION
 
 
 def test_product_never_imports_oracle():

@@ -387,7 +387,7 @@ def test_bench_single_gpu_line_carries_every_contract_field():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
+    assert len(lines) == 1 and r.stdout.strip() == lines[0]           # stdout carries the JSON line and nothing else
     d = json.loads(lines[0])
     assert d['metric'] == 'occupancy_queries_throughput' and d['unit'] == 'Mqueries/s' and d['value'] > 0
     assert d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['higher_is_better'] is True and d['vs_baseline'] is None
@@ -401,6 +401,9 @@ def test_bench_single_gpu_line_carries_every_contract_field():
     assert d['chunk_100000']['value'] > 0
     assert d['canonical_path']['gemm_roofline']['frac_at_measured_clock'] > 0
     assert d['canonical_path']['max_abs_diff_vs_headline_field'] < 1e-4
+    cn = d['calc_normal']                   # round 4: the colour loop's kernel path through the pixel tables and per point
+    assert cn['pixel_tables']['value'] > 0 and cn['per_point_gemms']['value'] > 0 and cn['max_abs_diff_between_paths'] < 2e-5
+    assert cn['pixel_tables']['gemm_flop_per_query_executed'] < cn['per_point_gemms']['gemm_flop_per_query_executed']
     g = d['gen_mesh']
     assert g['total_s'] > 0 and g['mc_check']['faces_bit_exact_vs_oracle'] and g['mc_check']['verts_bit_exact_vs_oracle']
     assert g['config5_1024']['resolution'] == 96 and g['config5_1024']['n_verts'] > 0

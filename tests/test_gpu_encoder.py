@@ -187,6 +187,23 @@ def test_full_size_encoders_to_occupancy_end_to_end(golden_dir):
     # is not vanishing (the reference divides by |g| + 1e-8)
     cos = (got_n * want_n).sum(0)
     assert np.median(cos) > 0.999 and (cos > 0.9).mean() > 0.97
+    # the same two calls through the pixel tables (forced on at this size; gen_mesh's calc_normal batches take them by
+    # default): same goldens of the reference's run, on the feature map the real encoder produced
+    from pifuhd_amd import _lib
+    _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_ALWAYS)
+    try:
+        netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)
+        preds_px = netMR.get_preds().cpu().numpy().reshape(-1)
+        low_px = netG.get_preds().cpu().numpy().reshape(-1)
+        netMR.calc_normal(pts[:, None, :, :m], calib[:, None], calib)
+        cos_px = (netMR.nmls.cpu().numpy()[0] * want_n).sum(0)
+    finally:
+        _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_AUTO)
+    print('through the pixel tables: max abs diff %.2e (coarse %.2e), %.2e from the per-point path' %
+          (np.abs(preds_px - want).max(), np.abs(low_px - gold['preds_low']).max(), np.abs(preds_px - preds).max()))
+    assert not np.array_equal(preds_px, preds)
+    assert np.abs(preds_px - want).max() < 1e-4 and np.abs(low_px - gold['preds_low']).max() < 1e-4
+    assert np.median(cos_px) > 0.999 and (cos_px > 0.9).mean() > 0.97
 
 
 def test_overlapped_encoder_schedule_is_bit_identical():

@@ -415,7 +415,17 @@ def test_query_with_nontrivial_calibrations(golden_dir, tag):
         outs.append(lat.cpu().numpy())
     assert np.abs(outs[0] - outs[1]).max() < 2e-5
     if tag == 'rot_y':
-        assert np.array_equal(outs[0], outs[1])             # x depends on z: both runs take the per-point path
+        # x depends on z: no column sharing.  The 19 200-point lattice takes the pixel tables (>= PIFU_PIXEL_TABLE_MIN_POINTS),
+        # the flagged run the per-point GEMMs; with the tables off the two runs are the same launches
+        assert not np.array_equal(outs[0], outs[1])
+        _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_OFF)
+        try:
+            lat = torch.empty(total, device='cuda')
+            _lib.call('pifu_eval_lattice', netMR._ctx.h, res, cinv.ctypes.data_as(C.c_void_p), c32.ctypes.data_as(C.c_void_p),
+                      None, 0, total, 1300, _lib.Q_FULL_COARSE, _ptr(lat), _stream_ptr(netMR.device))
+        finally:
+            _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_AUTO)
+        assert np.array_equal(lat.cpu().numpy(), outs[1])
 
 
 def test_full_pifu_supervised_forward_all_stacks(golden_dir):
@@ -517,7 +527,14 @@ def test_pixel_tables_follow_the_feature_map_and_the_flags():
         _lib.call('pifu_query', netMR._ctx.h, _ptr(pts), n, cal.ctypes.data_as(C.c_void_p), chunk, flags, _ptr(out), None, None,
                   _stream_ptr(netMR.device))
         return out.cpu().numpy()
-    pts = seeded_points(21, 3000, lim=1.05).cuda().contiguous()
+    pts = seeded_points(21, 3000, lim=1.05)
+    # points exactly on the map's border, on pixel centres and on the box faces: taps of weight 0 and taps outside the map
+    k = torch.arange(40, dtype=torch.float32)
+    pts[0, 0, :40] = (k % 8) / 3.5 - 1.0            # 8 columns from -1 to +1
+    pts[0, 1, :40] = (k // 8) / 2.0 - 1.0           # 5 rows from -1 to +1
+    pts[0, 2, :40] = torch.where(k % 2 == 0, torch.tensor(1.0), torch.tensor(-1.0))
+    pts[0, :2, 40:71] = (torch.arange(31, dtype=torch.float32) / 31 * 2 - 1)[None].expand(2, 31)      # centres of a 32-wide map
+    pts = pts.cuda().contiguous()
     try:
         for seed, hc in ((7, 32), (8, 20), (9, 32)):
             fc, ff = seeded_features(seed, hc=hc)
