@@ -174,7 +174,7 @@ def marching_cubes_slabs(ctx, volume, level, nslabs):
     return torch.cat(verts), torch.cat(faces)
 
 
-def transform_verts(ctx, verts_d, trans_mat):
+def transform_verts(ctx, verts_d, trans_mat, defer_host=False):
     """`(trans_mat[:3, :3] @ verts.T + trans_mat[:3, 3:4]).T` in float64 (`mesh_util.py:87-89`) on the device
     (`pifu_transform_verts`).  Returns (host float64 [V, 3], the same array as a device tensor).  The kernel evaluates each
     coordinate as the FMA chain `fma(m2, z, fma(m1, y, m0 * x))` followed by the addition of the translation - the order in
@@ -186,11 +186,15 @@ def transform_verts(ctx, verts_d, trans_mat):
     out_d = torch.empty(n, 3, device=verts_d.device, dtype=torch.float64)
     _lib.call('pifu_transform_verts', ctx.h, _ptr(verts_d), n, rows.ctypes.data_as(C.c_void_p), _ptr(out_d),
               _stream_ptr(ctx.device))
+    if defer_host:
+        host, ev = to_host_async(out_d)
+        return host, out_d, ev
     return to_host(out_d), out_d
 
 
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
-                   num_samples=10000, transform=None, return_sdf=False, sharded=False, return_device_verts=False):
+                   num_samples=10000, transform=None, return_sdf=False, sharded=False, return_device_verts=False,
+                   _defer_host=False):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
     values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
     [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty.
@@ -198,7 +202,9 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     (`pifuhd_amd.dist`); every rank gets the identical field; marching cubes runs redundantly on it, or - from
     `dist.SLAB_MC_MIN_RESOLUTION` on - one axis-0 slab per rank (`dist.marching_cubes_sharded`), with the same result.
     `return_device_verts=True` appends the float64 vertices as a device tensor (the colour loop of `gen_mesh` continues
-    from it without a host round trip)."""
+    from it without a host round trip).  `_defer_host=True` (gen_mesh): the vertex and face arrays cross to the host on
+    the copy stream while the caller goes on issuing work; a `HostCopies` is appended to the result, and the arrays' CONTENTS
+    are valid only after its `wait_faces()` / `wait_verts()`."""
     ctx = _ctx_of(net)
     from . import dist as pdist
     if sharded and pdist.collective_active():
@@ -223,22 +229,47 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     except (ValueError, RuntimeError):
         print('error cannot marching cubes')                                             # mesh_util.py:94-96
         return -1
-    faces = to_host(faces_d)
+    pending = HostCopies()
+    if _defer_host:
+        faces, pending.faces = to_host_async(faces_d)
+    else:
+        faces = to_host(faces_d)
     _, calib_inv = calib_pair(calib_tensor)
     mat = np.eye(4)
     mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
     mat[0:3, 3] = -1.0
     trans_mat = np.matmul(calib_inv, mat)
-    verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)                       # mesh_util.py:87-89
+    if _defer_host:
+        verts, verts_dev, pending.verts = transform_verts(ctx, verts_d, trans_mat, defer_host=True)   # mesh_util.py:87-89
+    else:
+        verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)
     if np.linalg.det(trans_mat[:3, :3]) < 0.0:
         faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
     normals = np.zeros((0, 3), np.float32)
     values = np.zeros((0,), np.float32)
+    out = (verts, faces, normals, values)
     if return_sdf:
-        return verts, faces, normals, values, sdf
-    if return_device_verts:
-        return verts, faces, normals, values, verts_dev
-    return verts, faces, normals, values
+        out += (sdf,)
+    elif return_device_verts:
+        out += (verts_dev,)
+    return out + (pending,) if _defer_host else out
+
+
+class HostCopies:
+    """The device-to-host copies `reconstruction(_defer_host=True)` left running on the copy stream."""
+
+    def __init__(self):
+        self.faces = self.verts = None
+
+    def wait_faces(self):
+        if self.faces is not None:
+            self.faces.synchronize()
+            self.faces = None
+
+    def wait_verts(self):
+        if self.verts is not None:
+            self.verts.synchronize()
+            self.verts = None
 
 
 _pinned = {}
@@ -269,7 +300,29 @@ def _drop_slab(slab):
     _slabs[:] = [s for s in _slabs if s is not slab]
 
 
+def to_host_async(t):
+    """`to_host` issued on the copy stream: returns (array, event) - the array's contents are valid once the event has
+    completed (`event.synchronize()`), the compute stream is not held up meanwhile - or (array, None) where `to_host` would
+    not use a pinned slab (small tensors, pool full or switched off): a finished, synchronous copy then."""
+    arr, view = _to_host(t, issue=False)
+    if view is None:
+        return arr, None
+    dev = t.device
+    side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        view.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    t.record_stream(side)
+    return arr, ev
+
+
 def to_host(t):
+    return _to_host(t)[0]
+
+
+def _to_host(t, issue=True):
     """Device tensor -> host array OF THE CALLER'S OWN, without a fresh pageable allocation per call (a 100 MB result costs
     ~25 000 page faults plus a staged copy each time): the copy lands in a pinned slab, and the returned array is a view of
     it.  A slab is handed out again only once the array it backed is gone - arrays and every view of them are tracked
@@ -283,7 +336,7 @@ def to_host(t):
     t = t.contiguous()
     nbytes = t.numel() * t.element_size()
     if nbytes < (4 << 20) or not POOL_RESULTS:
-        return t.cpu().numpy()
+        return t.cpu().numpy(), None
     want = nbytes + nbytes // 4
     slot = None
     for s in list(_slabs):
@@ -300,14 +353,15 @@ def to_host(t):
             if s[1]() is None and _pool_bytes() + want > POOL_MAX_BYTES:
                 _drop_slab(s)
         if len(_slabs) >= POOL_MAX_SLABS or _pool_bytes() + want > POOL_MAX_BYTES:
-            return t.cpu().numpy()
+            return t.cpu().numpy(), None
         slot = [torch.empty(want, dtype=torch.uint8, pin_memory=True), lambda: None]
         _slabs.append(slot)
     view = slot[0][:nbytes].view(t.dtype).view(t.shape)
-    view.copy_(t)
+    if issue:
+        view.copy_(t)
     arr = view.numpy()
     slot[1] = weakref.ref(arr)
-    return arr
+    return arr, view            # (`issue=False`: the caller copies into `view` itself, to_host_async)
 
 
 def _pin_key(tag, dev):

@@ -143,7 +143,7 @@ class _Subject:
 
 
 def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None,
-             sharded=False, _pipeline=True):
+             sharded=False, _pipeline=True, _defer_host=True):
     """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.
 
     `sharded=True` (not in the reference, which is single-device): every rank of the initialised
@@ -210,16 +210,22 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
             # calc_normal calls go to the GPU in groups of ten whole 50 000-vertex calls; each group's colours cross to pinned
             # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
             # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
-            # own threads while the GPU works on the next group.  (Measured and dropped: the vertex / face host copies as
-            # asynchronous transfers into pinned buffers beside the colour loop - the extra 200 MB of host copies they need to
-            # hand arrays of their own back to the caller cost more than the 15 ms of transfer they hide.)
+            # own threads while the GPU works on the next group.
+            # The 200 MB of vertex / face arrays cross to the host on the copy stream - into the pinned slabs that ARE the
+            # result arrays (`mesh_util.to_host_async`: no second host copy, which is what made this a loss in round 3) - while
+            # the first group of the colour loop computes: `faces` is waited for once that group is queued, `verts` before the
+            # OBJ layout needs the positions.  The compute stream used to idle for the 12 ms of these copies.
             # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
             # reference (reconstruction.py:56)
-            verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
-                                                           use_octree=use_octree, num_samples=5000, sharded=sharded,
-                                                           return_device_verts=True)
+            verts, faces, _, _, verts_dev, host_copies = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max,
+                                                                        thresh, use_octree=use_octree, num_samples=5000,
+                                                                        sharded=sharded, return_device_verts=True,
+                                                                        _defer_host=True)
+            if not _defer_host:       # tools/genmesh_ab.py: the copies waited for at once, as before round 4
+                host_copies.wait_faces()
+                host_copies.wait_verts()
             t3 = mark()
-            obj = ObjFile(save_path, faces)                           # the face lines are formatted while the colours are computed
+            obj = None
             n_verts = len(verts)
             spans = _normal_spans(n_verts)
             if spans_check(spans):
@@ -241,6 +247,10 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
                     ev.record(side)
                 col_d.record_stream(side)
                 done.append((l, r, ev))
+                if obj is None:
+                    host_copies.wait_faces()
+                    obj = ObjFile(save_path, faces)                   # the face lines are formatted while the colours are computed
+            host_copies.wait_verts()
             obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
             color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
             for (l, r, ev) in done:
