@@ -68,6 +68,14 @@ def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
     assert lib.load().pifu_abi_version() == lib.ABI_VERSION
 
 
+def test_graft_entry_build_passes():
+    """The driver's "does it build" check (`__graft_entry__.build()`): every library compiles for gfx950 without a GPU and
+    the binding accepts what was built (its ABI version included)."""
+    import importlib
+    entry = importlib.import_module('__graft_entry__')
+    entry.build()
+
+
 def test_product_never_imports_oracle():
     """No file of the product package imports, loads or links anything under oracle/."""
     pkg = os.path.join(ROOT, 'rgb-d-pifuhd_amd')
