@@ -77,7 +77,8 @@ enum {
  *      pifu_face_components is a bit mask; the `all_stacks` argument of pifu_filter_coarse became the PIFU_ENC_* flags word.
  *   3: round 4 - explicit point lists (pifu_query, pifu_calc_normal*) of PIFU_PIXEL_TABLE_MIN_POINTS points or more take the
  *      coarse level's image-feature products from per-pixel tables (PIFU_Q_NO_COLUMN_SHARING keeps the per-point GEMMs);
- *      pifu_enc_join semantics: every stream that asks before the deferred hourglass has finished waits for it. */
+ *      pifu_enc_join semantics: every stream that asks before the deferred hourglass has finished waits for it;
+ *      pifu_set_pixel_tables, pifu_set_workspace_limit added. */
 #define PIFU_ABI_VERSION 3
 const char *pifu_last_error(void);
 int pifu_abi_version(void);
@@ -89,6 +90,13 @@ int pifu_ctx_destroy(pifu_ctx *ctx);
  * the timed region after the first call).  Synchronises. */
 int pifu_reserve(pifu_ctx *ctx, int64_t rows);
 int64_t pifu_workspace_bytes(pifu_ctx *ctx);
+/* Bound the query workspace (the arena of one batch of launches, ~12.5 KB per padded point row) to `bytes`; 0 = no bound
+ * (default).  A call whose batch would exceed the bound - or whose allocation the device refuses - runs in more, smaller
+ * batches of whole chunks instead: the same numbers (a chunk never depends on the batch it runs in), a few per cent slower
+ * below ~0.25 M rows.  One chunk is the floor: PIFU_ERR_NOMEM if even that does not fit.  An arena already larger than the
+ * bound is released (synchronises).  For devices shared with other work; the marching-cubes, octree and table arenas
+ * (R^3-sized) are not covered. */
+int pifu_set_workspace_limit(pifu_ctx *ctx, int64_t bytes);
 
 /* ---- SurfaceClassifier definition: replaces MLP.__init__ / load_state_dict (MLP.py:12-41) ---- */
 /* dims = filter_channels, res_layers = skip-concat layers, merge_layer as passed to MLP() (<=0 means

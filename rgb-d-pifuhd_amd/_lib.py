@@ -43,6 +43,7 @@ SIGNATURES = {
     'pifu_ctx_destroy': (_i32, [_p]),
     'pifu_reserve': (_i32, [_p, _i64]),
     'pifu_workspace_bytes': (_i64, [_p]),
+    'pifu_set_workspace_limit': (_i32, [_p, _i64]),
     'pifu_mlp_define': (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32]),
     'pifu_mlp_set_layer': (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'pifu_set_precision': (_i32, [_p, _i32]),

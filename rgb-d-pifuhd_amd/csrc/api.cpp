@@ -48,6 +48,7 @@ int pifu_ensure(DevBuf &b, size_t bytes)
         e = hipMalloc(&b.p, bytes);
         if (e != hipSuccess) {
             pifu_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();          // reported through the return code: nothing is left behind for a later check
             b.p = nullptr;
             return PIFU_ERR_NOMEM;
         }
@@ -215,6 +216,22 @@ extern "C" int pifu_reserve(pifu_ctx *ctx, int64_t rows)
 {
     PIFU_REQUIRE(ctx && rows > 0, PIFU_ERR_INVALID, "pifu_reserve: bad argument");
     ctx->ws_rows = round_up(rows, PIFU_BM);
+    return PIFU_OK;
+}
+
+// upper bound of the query workspace (the arena of a batch of launches); 0 = none.  A smaller bound means more, smaller
+// batches of launches with the same results; an existing larger arena is released
+extern "C" int pifu_set_workspace_limit(pifu_ctx *ctx, int64_t bytes)
+{
+    PIFU_REQUIRE(ctx && bytes >= 0, PIFU_ERR_INVALID, "pifu_set_workspace_limit: bad argument");
+    ctx->ws_limit = bytes;
+    if (bytes > 0 && ctx->arena.bytes > (size_t)bytes && ctx->arena.p) {
+        PIFU_HIP(hipSetDevice(ctx->device));
+        PIFU_HIP(hipDeviceSynchronize());
+        PIFU_HIP(hipFree(ctx->arena.p));
+        ctx->arena.p = nullptr;
+        ctx->arena.bytes = 0;
+    }
     return PIFU_OK;
 }
 

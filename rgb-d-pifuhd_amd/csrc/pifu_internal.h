@@ -108,6 +108,7 @@ struct pifu_ctx {
     // query workspace (grown lazily; everything lives in one arena)
     DevBuf arena;
     int64_t ws_rows = 0;
+    int64_t ws_limit = 0;                 // pifu_set_workspace_limit: bytes the query workspace may take (0 = no limit)
     // marching-cubes workspace
     DevBuf mc_arena;
     McState mc;

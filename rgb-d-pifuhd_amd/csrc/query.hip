@@ -1907,7 +1907,7 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     int64_t batch_chunks = target_rows / P;
     if (batch_chunks < 1) batch_chunks = 1;
     if (batch_chunks > total_chunks) batch_chunks = total_chunks;
-    const int64_t rows_cap = batch_chunks * P;
+    int64_t rows_cap = batch_chunks * P;
     const int64_t normal_pts = src_mode == 3 ? n : 0;
     // column sharing applies when the projected (x, y) of a lattice point does not depend on k
     bool colmode = (src_mode == 1 || src_mode == 2) && ctx->col_enable && !(flags & PIFU_Q_NO_COLUMN_SHARING) &&
@@ -1946,8 +1946,21 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             if (mc.layer[i].cin_feat) hi = mc.layer[i].col_off + (int)round_up(mc.layer[i].cout, BN);
         pxm.nS = (hi - pxm.g1) / BN;
     }
-    Plan probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
-    rc = pifu_ensure(ctx->arena, probe.bytes);
+    // The workspace of a batch of launches: when it exceeds pifu_set_workspace_limit, or the device cannot provide it, the
+    // batch is halved (whole chunks) until it fits - more, smaller batches of launches, the same numbers (a chunk never
+    // depends on which batch it runs in).  One chunk is the floor.
+    Plan probe;
+    for (;;) {
+        probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
+        const bool over = ctx->ws_limit > 0 && probe.bytes > (size_t)ctx->ws_limit && probe.bytes > ctx->arena.bytes;
+        rc = over ? PIFU_ERR_NOMEM : pifu_ensure(ctx->arena, probe.bytes);
+        if (rc != PIFU_ERR_NOMEM || batch_chunks <= 1) break;
+        batch_chunks = (batch_chunks + 1) / 2;
+        rows_cap = batch_chunks * P;
+    }
+    if (rc == PIFU_ERR_NOMEM && ctx->ws_limit > 0 && probe.bytes > (size_t)ctx->ws_limit)
+        pifu_set_error("one chunk of %lld points needs %zu bytes of workspace, the limit is %lld (pifu_set_workspace_limit)",
+                       (long long)eff_chunk, probe.bytes, (long long)ctx->ws_limit);
     if (rc != PIFU_OK) return rc;
     Plan pl = carve(ctx, (char *)ctx->arena.p, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
 

@@ -578,3 +578,47 @@ def test_calc_normal_with_pixel_tables():
     assert np.abs(p0 - p1).max() < 2e-5
     cos = (n0 * n1).sum(0)
     assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.9
+
+
+def test_workspace_limit_runs_smaller_batches_with_identical_results():
+    """`pifu_set_workspace_limit`: a call whose batch of launches would need more workspace than the bound runs in more,
+    smaller batches of whole chunks - bit-identical results on the lattice path (column sharing + depth walk), on explicit
+    points through the pixel tables and on calc_normal; a bound below one chunk's need is PIFU_ERR_NOMEM, not a crash."""
+    import ctypes as C
+    from pifuhd_amd import _lib, mesh_util
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    netG, netMR, *_ = _build()
+    h = netMR._ctx.h
+    calib = calib_tensor()
+    c32, cinv = mesh_util.calib_pair(calib)
+    res = (C.c_int32 * 3)(64, 64, 64)
+    total = 64 ** 3
+    pts = seeded_points(31, 40000, lim=1.05).cuda().contiguous()
+    verts = seeded_points(32, 30000, lim=0.9)
+
+    def run_all():
+        lat = torch.empty(total, device='cuda')
+        _lib.call('pifu_eval_lattice', h, res, cinv.ctypes.data_as(C.c_void_p), c32.ctypes.data_as(C.c_void_p), None, 0, total, 5000,
+                  _lib.Q_FULL_COARSE, _ptr(lat), _stream_ptr(netMR.device))
+        out = torch.empty(40000, device='cuda')
+        _lib.call('pifu_query', h, _ptr(pts), 40000, c32.ctypes.data_as(C.c_void_p), 5000, 0, _ptr(out), None, None,
+                  _stream_ptr(netMR.device))
+        netMR.calc_normal_chunked(verts[:, None], calib[:, None], calib, interval=2500)      # 10 000 rows per GroupNorm batch
+        return lat.clone(), out.clone(), netMR.nmls[0].clone()
+    want = run_all()
+    big = _lib.load().pifu_workspace_bytes(h)
+    try:
+        _lib.call('pifu_set_workspace_limit', h, 160 << 20)             # 160 MB: ~12 000 rows per batch instead of 262 144
+        got = run_all()
+        assert _lib.load().pifu_workspace_bytes(h) < big and _lib.load().pifu_workspace_bytes(h) < (160 << 20) + (300 << 20)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        _lib.call('pifu_set_workspace_limit', h, 1 << 20)               # below one 5 000-point chunk's 66 MB
+        with pytest.raises(_lib.PifuError) as e:
+            run_all()
+        assert e.value.code == _lib.ERR_NOMEM and 'pifu_set_workspace_limit' in e.value.message
+    finally:
+        _lib.call('pifu_set_workspace_limit', h, 0)
+    again = run_all()
+    for a, b in zip(want, again):
+        assert torch.equal(a, b)
