@@ -46,7 +46,7 @@ def read_prof(_lib, h, which, reset=1):
 
 
 def reset_prof(_lib, h):
-    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC):
+    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC, _lib.PROF_ENC):
         _lib.call('pifu_profile_read', h, which, None, None, None, 1)
 
 
@@ -141,8 +141,15 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
+    # N processes share this host: each one's OBJ writer / PNG encoder gets its share of the cores, not all of them
+    host_threads = max(2, (os.cpu_count() or 8) // max(world, 1))
+    recon.set_host_threads(host_threads)
+    res['host_threads_per_rank'] = host_threads
+    extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds')
+
     with tempfile.TemporaryDirectory() as td:
-        # (a) sharded: identical inputs on every rank, so a failure is the same on every rank
+        # (a) sharded: identical inputs on every rank, so a failure is the same on every rank.  Rank 0 streams the OBJ and is
+        # the only rank that copies the mesh to the host (result_on='rank0', the default)
         timings, err, t_tot = {}, None, float('inf')
         try:
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'warm{rank}.obj'), sharded=True)      # at the timed size
@@ -153,18 +160,27 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             t_tot = time.perf_counter() - t0
         except Exception as e:
             err = repr(e)
-        red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
+        red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys] + [float(timings.get('collective_s', 0.0))])
         if err is None and red[0] != float('inf'):
-            res['one_subject_sharded'] = {'total_s': round(red[0], 4), **{k: round(v, 4) for k, v in zip(keys, red[1:])},
-                                          'n_verts': timings.get('n_verts'), 'n_faces': timings.get('n_faces')}
+            res['one_subject_sharded'] = {'world': world, 'total_s': round(red[0], 4), **{k: round(v, 4) for k, v in zip(keys, red[1:])},
+                                          'n_verts': timings.get('n_verts'), 'n_faces': timings.get('n_faces'),
+                                          'result_on': 'rank0',
+                                          # rank 0's own view of the exchange: one all-gather of the fp32 predictions per octree
+                                          # level + one of the colours per round; the time between the events around them
+                                          # includes waiting for the slowest rank; max over ranks beside it
+                                          **{k: timings.get(k) for k in extra}, 'collective_s_max_over_ranks': round(red[-1], 5)}
             log(f"gen_mesh sharded: {red[0]:.3f} s")
         else:
             res['one_subject_sharded'] = {'error': err or 'failed on another rank'}
-        # (b) independent subjects (different images: a failure may be local to one rank)
+        # (b) independent subjects (different images: a failure may be local to one rank).  One untimed call with the rank's
+        # own image first: the first call with a new mesh size allocates (pinned result slabs, arenas), which is not the
+        # steady state of a recon() loop over many subjects
         err, t_tot = None, float('inf')
         try:
             own = synth.synthetic_inputs(1024, args.image_channels, seed=rank)
-            torch.cuda.synchronize(dev)
+            recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subjwarm{rank}.obj'))
+            os.remove(os.path.join(td, f'subjwarm{rank}.obj'))
+            fence()
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subj{rank}.obj'))
             torch.cuda.synchronize(dev)
@@ -173,7 +189,8 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             err = repr(e)
         red = reduce_max([t_tot])
         if red[0] != float('inf'):
-            res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3)}
+            res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3),
+                                           'warmed': True}
         else:
             res['independent_subjects'] = {'error': err or 'failed on another rank'}
         # (c) BASELINE configs[4]: ONE subject at 1024^3, octree levels sharded by chunk ranges with one all-gather per level,
@@ -185,11 +202,11 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             try:
                 net5 = smoother_subject(args, dev, data)
                 fence()
-                recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'warm5_{rank}.obj'), sharded=True)
+                recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'warm5_{rank}.obj'), sharded=True, result_on='all')
                 fence()
                 t0 = time.perf_counter()
                 mesh = recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'mesh5_{rank}.obj'), timings=timings,
-                                      sharded=True)
+                                      sharded=True, result_on='all')      # every rank returns the mesh: their digests are compared
                 fence()
                 t_tot = time.perf_counter() - t0
                 sha = mesh_digest(*mesh)
@@ -197,6 +214,8 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             except Exception as e:
                 err = repr(e)
             red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
+            if err is not None:
+                log(f'config 5 failed on this rank: {err}')
             # every rank must hold the same mesh: max(sha) == min(sha) over the ranks (56 bits of the sha256 of vertices,
             # faces and colours)
             t = torch.tensor([sha, -sha], device=dev, dtype=torch.int64)
@@ -206,7 +225,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                 res['config5_1024'] = {
                     'resolution': args.config5_res, 'subject': 'smoother (mlp_weight_std 0.02)', 'total_s': round(red[0], 4),
                     **{k: round(v, 4) for k, v in zip(keys, red[1:])}, 'n_verts': timings.get('n_verts'),
-                    'n_faces': timings.get('n_faces'),
+                    'n_faces': timings.get('n_faces'), 'result_on': 'all', **{k: timings.get(k) for k in extra},
                     'marching_cubes': 'one axis-0 slab per rank' if args.config5_res >= pdist.SLAB_MC_MIN_RESOLUTION
                     else 'replicated (below dist.SLAB_MC_MIN_RESOLUTION)',
                     'mesh_identical_on_all_ranks': bool(int(t[0]) == -int(t[1])), 'mesh_sha256_56bit': '%014x' % int(t[0])}
@@ -309,9 +328,17 @@ def main():
         print(f'[bench r{rank} {time.perf_counter() - t_start:7.1f}s] {msg}', file=sys.stderr, flush=True)
     log('weights ready')
     data = synth.synthetic_inputs(1024, args.image_channels, seed=0)      # one subject: every rank holds the same image + weights
+    cold = {}
     if args.features == 'filter':
-        netMR.filter_global(data['img_512'].to(dev))
-        netMR.filter_local(data['img'].to(dev)[:, None])
+        # the first pass packs and uploads the encoder weights (1.5 GB: netF / netB 0.73 GB each) - what a one-image run_recon.py
+        # style invocation pays; the second pass is the steady state
+        torch.cuda.synchronize(dev)
+        for key in ('first_encoder_pass_s', 'second_encoder_pass_s'):
+            c0 = time.perf_counter()
+            netMR.filter_global(data['img_512'].to(dev))
+            netMR.filter_local(data['img'].to(dev)[:, None])
+            torch.cuda.synchronize(dev)
+            cold[key] = round(time.perf_counter() - c0, 4)
     else:
         gfe = torch.Generator().manual_seed(4242)
         netG.set_features(torch.randn(1, 256, 128, 128, generator=gfe))
@@ -622,6 +649,40 @@ def main():
                 _lib.call('pifu_profile_enable', h, 0)
                 _lib.call('pifu_set_precision', h, 0)
 
+    # ---- the encoder pass (filter_global + filter_local of one image, the overlapped schedule gen_mesh uses): counted
+    # convolution FLOPs / wall time of a steady-state pass against the fp32-matrix peak
+    if world == 1 and args.features == 'filter':
+        try:
+            from pifuhd_amd import reconstruction as recon_enc
+            recon_enc._Subject(netMR, data)
+            fence()
+            reset_prof(_lib, h)
+            _lib.call('pifu_profile_enable', h, 1)
+            passes = []
+            for _ in range(5):
+                e0 = time.perf_counter()
+                recon_enc._Subject(netMR, data)
+                torch.cuda.synchronize(dev)
+                passes.append(time.perf_counter() - e0)
+            _lib.call('pifu_profile_enable', h, 0)
+            _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)
+            en_fl /= len(passes)
+            p_med = sorted(passes)[len(passes) // 2]
+            secondary.append({
+                'kernel': 'encoders: k_conv_dma<64|32> (+ k_prep_act, statistics, split-K reduce) of filter_global + filter_local, one image',
+                'bound': 'mfma', 'achieved': round(en_fl / p_med / 1e12, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(en_fl / p_med / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4), 'pass_ms': round(p_med * 1e3, 3),
+                'passes_ms': [round(p * 1e3, 3) for p in passes], 'conv_launches_per_pass': en_n // len(passes),
+                'alg_tflop_per_pass': round(en_fl / 1e12, 4),
+                'definition': 'host image -> both feature maps resident (upload of the 1024 px image included), wall clock of a '
+                              'steady-state pass; FLOPs = 2 * output pixels * Cout * Cin * taps summed over the convolutions (counted by the library)'})
+            cold['steady_encoder_pass_s'] = round(p_med, 4)
+            log(f"encoders: {p_med * 1e3:.2f} ms per image, {en_fl / p_med / 1e12:.1f} TFLOP/s")
+        except Exception as e:
+            secondary.append({'kernel': 'encoders', 'error': repr(e)})
+        finally:
+            _lib.call('pifu_profile_enable', h, 0)
+
     # ---- parity spot check + CPU baseline (oracle = checker; never the thing measured as `value`) -----
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pifu_oracle as O
@@ -670,9 +731,12 @@ def main():
             try:
                 # warm-up at the timed size: the marching-cubes arena, the octree state and the pinned result buffers of a
                 # 512^3 mesh are allocated here, as they are for every subject after the first one of a recon() loop
-                recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm.obj'))
-                log('gen_mesh warm-up done')
                 torch.cuda.synchronize(dev)
+                w0 = time.perf_counter()
+                recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm.obj'))
+                torch.cuda.synchronize(dev)
+                cold['first_gen_mesh_call_s'] = round(time.perf_counter() - w0, 4)
+                log(f"gen_mesh warm-up done (first call at this size: {cold['first_gen_mesh_call_s']} s)")
                 reset_prof(_lib, h)
                 _lib.call('pifu_profile_enable', h, 1)
                 runs = []
@@ -684,11 +748,50 @@ def main():
                 _lib.call('pifu_profile_enable', h, 0)
                 mc_ms, mc_n, mc_bytes = read_prof(_lib, h, _lib.PROF_MC)
                 mc_ms, mc_bytes = mc_ms / len(runs), mc_bytes / len(runs)
+                gm_ms, gm_n, gm_fl = read_prof(_lib, h, _lib.PROF_GEMM)          # the MLP GEMM launches of the timed runs
+                _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)               # the encoders' convolutions (counted, not timed)
+                gm_ms, gm_n, gm_fl, en_n, en_fl = gm_ms / len(runs), gm_n // len(runs), gm_fl / len(runs), en_n // len(runs), en_fl / len(runs)
                 timings = sorted(runs, key=lambda t: t['total_s'])[len(runs) // 2]      # the median run, phase by phase
                 out['gen_mesh'] = {'resolution': args.genmesh_res, 'use_octree': True,
                                    **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
                                    'total_s_is': 'median of the runs below (each a complete gen_mesh call incl. both encoders, '
-                                                 'PNG and OBJ)', 'runs_total_s': [round(t['total_s'], 4) for t in runs]}
+                                                 'PNG and OBJ)', 'runs_total_s': [round(t['total_s'], 4) for t in runs],
+                                   'first_call_s': cold.get('first_gen_mesh_call_s')}
+                # M2 on the roofline (BASELINE.json: 'absolute and as fraction of the HBM/MFMA roofline'): the call is bound by
+                # the fp32 matrix pipe - MLP GEMMs of the octree levels and of the colour loop + the encoders' convolutions;
+                # frac = executed algorithmic FLOPs of ONE call / its wall time / the 157.3 TFLOP/s fp32-matrix peak.  One more
+                # (untimed: each read synchronises) call splits the GEMM work by phase.
+                tot = timings['total_s']
+                ro = {'bound': 'mfma', 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                      'executed_tflop_per_call': round((gm_fl + en_fl) / 1e12, 3),
+                      'mlp_gemm_tflop_per_call': round(gm_fl / 1e12, 3), 'mlp_gemm_launches_per_call': gm_n,
+                      'encoder_conv_tflop_per_call': round(en_fl / 1e12, 3), 'encoder_conv_launches_per_call': en_n,
+                      'achieved': round((gm_fl + en_fl) / tot / 1e12, 2),
+                      'frac': round((gm_fl + en_fl) / tot / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                      'mlp_gemm_busy_s_per_call': round(gm_ms * 1e-3, 4),
+                      'mlp_gemm_busy_share_of_call': round(gm_ms * 1e-3 / tot, 4),
+                      'mlp_gemm_frac_while_busy': round(gm_fl / (gm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if gm_ms > 0 else None,
+                      'definition': 'ALGORITHMIC FLOPs executed by one gen_mesh call (k_mlp_gemm_tri launches: 2 * valid points * Cout '
+                                    '* Cin; encoder convolutions: 2 * output pixels * Cout * Cin * taps) / total_s / peak; busy = summed '
+                                    'HIP-event durations of the GEMM launches'}
+                try:
+                    reset_prof(_lib, h)
+                    _lib.call('pifu_profile_enable', h, 1)
+                    tp = {'profile_phases': True}
+                    recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'phases.obj'), timings=tp)
+                    _lib.call('pifu_profile_enable', h, 0)
+                    os.remove(os.path.join(td, 'phases.obj'))
+                    for ph in ('reconstruction', 'normals'):
+                        fl, ms, sec = tp['gemm_flop_' + ph], tp['gemm_ms_' + ph], timings[ph + '_s']
+                        ro[ph] = {'mlp_gemm_tflop': round(fl / 1e12, 3), 'phase_s': round(sec, 4), 'mlp_gemm_busy_s': round(ms * 1e-3, 4),
+                                  'frac': round(fl / sec / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                  'frac_while_busy': round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if ms > 0 else None}
+                    ro['encoders'] = {'conv_tflop': round(en_fl / 1e12, 3), 'phase_s': round(timings['filter_s'], 4),
+                                      'frac': round(en_fl / timings['filter_s'] / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4)}
+                except Exception as e:
+                    ro['phase_split_error'] = repr(e)
+                out['gen_mesh']['roofline'] = ro
+                log(f"gen_mesh roofline: {ro['executed_tflop_per_call']} TFLOP in {tot:.3f} s = {ro['achieved']} TFLOP/s = {ro['frac']} of peak")
                 if mc_ms > 0:
                     ach = mc_bytes / (mc_ms * 1e-3) / 1e9
                     secondary.append({
@@ -856,6 +959,9 @@ def main():
                     out['cpu_baseline_gen_mesh_error'] = repr(e)
     if secondary:
         out['roofline_secondary'] = secondary
+    if cold:
+        out['cold_start'] = {**cold, 'note': 'first_encoder_pass_s includes packing + uploading 1.5 GB of encoder weights; '
+                             'first_gen_mesh_call_s is the first call at the timed resolution (arenas, pinned result slabs, pixel table)'}
     if multi is not None:
         out['gen_mesh'] = multi
     if rccl_summary:

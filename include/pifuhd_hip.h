@@ -78,8 +78,12 @@ enum {
  *   3: round 4 - explicit point lists (pifu_query, pifu_calc_normal*) of PIFU_PIXEL_TABLE_MIN_POINTS points or more take the
  *      coarse level's image-feature products from per-pixel tables (PIFU_Q_NO_COLUMN_SHARING keeps the per-point GEMMs);
  *      pifu_enc_join semantics: every stream that asks before the deferred hourglass has finished waits for it;
- *      pifu_set_pixel_tables, pifu_set_workspace_limit added. */
-#define PIFU_ABI_VERSION 3
+ *      pifu_set_pixel_tables, pifu_set_workspace_limit added.
+ *   4: round 5 - the automatic pixel-table threshold follows the coarse map (calls of at least max(16 384, H * W) points: the
+ *      same as before for the 128^2 map, later for larger maps); pifu_set_workspace_limit is a hard bound of the query arena (no allocation slack);
+ *      pifu_arena_bytes, pifu_set_host_threads and the pifu_comm_* / pifu_allgather_* calls added;
+ *      a context may be used from several streams: the pixel table is ordered against its builder and its readers by events. */
+#define PIFU_ABI_VERSION 4
 const char *pifu_last_error(void);
 int pifu_abi_version(void);
 
@@ -97,6 +101,12 @@ int64_t pifu_workspace_bytes(pifu_ctx *ctx);
  * bound is released (synchronises).  For devices shared with other work; the marching-cubes, octree and table arenas
  * (R^3-sized) are not covered. */
 int pifu_set_workspace_limit(pifu_ctx *ctx, int64_t bytes);
+/* Bytes one of the context's device arenas holds at the moment (pifu_workspace_bytes is their sum). */
+enum { PIFU_ARENA_QUERY = 0, PIFU_ARENA_MC = 1, PIFU_ARENA_OCTREE = 2, PIFU_ARENA_COLUMN = 3, PIFU_ARENA_PIXEL = 4, PIFU_ARENA_MISC = 5 };
+int64_t pifu_arena_bytes(pifu_ctx *ctx, int which);
+/* Host worker threads the library may start per call (the OBJ writer's formatting / writing threads): 0 = as many as the
+ * machine has, at most 32 (default).  Process-wide.  For several processes sharing one host (one per GPU): cpu_count / ranks. */
+int pifu_set_host_threads(int n);
 
 /* ---- SurfaceClassifier definition: replaces MLP.__init__ / load_state_dict (MLP.py:12-41) ---- */
 /* dims = filter_channels, res_layers = skip-concat layers, merge_layer as passed to MLP() (<=0 means
@@ -119,7 +129,9 @@ int pifu_set_precision(pifu_ctx *ctx, int mode);
  * W * sum_t w_t F[tap_t] = sum_t w_t (W * F[tap_t]): the table G = W * F is computed once per feature map (H * W pixel rows)
  * and a point blends four rows of it instead of running a K = 256 GEMM per point - 23 % fewer FLOPs on the calc_normal path,
  * same result up to fp32 summation order (~1e-6 on the occupancy).  mode 0: never; 1 (default): for calls of at least
- * PIFU_PIXEL_TABLE_MIN_POINTS points; 2: always.  PIFU_Q_NO_COLUMN_SHARING on a call keeps the per-point GEMMs whatever the
+ * PIFU_PIXEL_TABLE_MIN_POINTS points AND at least H * W points (the map's pixel count: below it building the table costs more
+ * than the per-point GEMMs it replaces; once built it serves every later call on the same map) - the two coincide for the
+ * reference's 128 x 128 map; 2: always.  PIFU_Q_NO_COLUMN_SHARING on a call keeps the per-point GEMMs whatever the
  * mode.  The table (H * W x 1536 floats: 100 MB for the 128^2 map) lives in the context and is rebuilt when the coarse
  * feature map, the coarse MLP or the precision mode changes. */
 #define PIFU_PIXEL_TABLE_MIN_POINTS 16384
@@ -225,6 +237,22 @@ int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, int n0, int n
 int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base, int32_t *halo_out, pifu_stream stream);
 int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pifu_stream stream);
 
+/* ---- the exchange step of the sharded evaluation (the reference is single-device) -------------------------------
+ * One process per GPU evaluates a contiguous range of whole chunks of a grid / octree level's point list and ONE all-gather
+ * of the fp32 predictions rebuilds the list on every rank (rgb-d-pifuhd_amd/dist.py: torch.distributed does it for the Python
+ * binding; these calls are the same collective for bindings without it).  A thin wrapper over RCCL's ncclAllGather; RCCL is
+ * looked up at run time (the copy already loaded into the process, else /opt/rocm's), PIFU_ERR_STATE if there is none.
+ * pifu_comm_unique_id: rank 0 draws the id and hands the 128 bytes to the other ranks over any side channel;
+ * pifu_comm_create: collective over all `world` ranks (one per device); pifu_allgather_f32: recv [world][count_per_rank]
+ * receives rank r's send [count_per_rank] at row r, enqueued on `stream` (recv + rank * count_per_rank == send is allowed). */
+typedef struct pifu_comm pifu_comm;
+#define PIFU_COMM_ID_BYTES 128
+int pifu_comm_unique_id(uint8_t id[PIFU_COMM_ID_BYTES]);
+int pifu_comm_create(int device, int rank, int world, const uint8_t id[PIFU_COMM_ID_BYTES], pifu_comm **out);
+int pifu_comm_destroy(pifu_comm *comm);
+int pifu_allgather_f32(pifu_comm *comm, const float *send, float *recv, int64_t count_per_rank, pifu_stream stream);
+int pifu_allgather_bytes(pifu_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, pifu_stream stream);
+
 /* ---- per-vertex normals: PIFuMRNet.calc_normal (PIFuMRNet.py:188-243) as used by gen_mesh -------- */
 /* verts: device fp32 [3][n]; every call is ONE GroupNorm batch of 4n points (p, p+dx, p+dy, p+dz
  * interleaved per point); normals: device fp32 [3][n] unit normals; pred4 (device fp32 [4n], may be NULL) receives the
@@ -292,9 +320,11 @@ int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, 
  * 2 * valid points * Cout * Cin), PIFU_PROF_SAMPLER = every per-point k_sample launch (work = algorithmic bytes: 4 taps x
  * channels gathered + one MLP input row written per valid point), PIFU_PROF_MC = the marching-cubes kernels of
  * pifu_mc_count + pifu_mc_emit (two timed spans per mesh; work = one pass over the volume, n0 * n1 * n2 * sizeof(value), plus the
- * 12-byte vertices and faces written).
+ * 12-byte vertices and faces written), PIFU_PROF_ENC = the convolutions of pifu_filter_coarse / pifu_filter_fine (work =
+ * ALGORITHMIC FLOPs, 2 * output pixels * Cout * Cin * taps; they run on up to three concurrent streams of the library, so they are
+ * counted, not timed: ms = 0 - time the pass as a whole).
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms), launches, work. */
-enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2 };
+enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2, PIFU_PROF_ENC = 3 };
 int pifu_profile_enable(pifu_ctx *ctx, int on);
 int pifu_profile_read(pifu_ctx *ctx, int which, double *ms, int64_t *launches, double *work, int reset);
 

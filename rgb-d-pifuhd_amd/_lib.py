@@ -10,16 +10,18 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libpifuhd_hip.so')
 
-ABI_VERSION = 3          # PIFU_ABI_VERSION of include/pifuhd_hip.h this binding was written against
+ABI_VERSION = 4          # PIFU_ABI_VERSION of include/pifuhd_hip.h this binding was written against
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
-PROF_GEMM, PROF_SAMPLER, PROF_MC = 0, 1, 2
+PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC = 0, 1, 2, 3
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
 ENC_ALL_STACKS, ENC_DEFER_JOIN = 1, 2
 PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables
-PIXEL_TABLE_MIN_POINTS = 16384
+PIXEL_TABLE_MIN_POINTS = 16384            # the automatic threshold: max(this, H * W of the coarse map) points per call
+ARENA_QUERY, ARENA_MC, ARENA_OCTREE, ARENA_COLUMN, ARENA_PIXEL, ARENA_MISC = 0, 1, 2, 3, 4, 5
+COMM_ID_BYTES = 128
 
 
 class PifuError(RuntimeError):
@@ -44,6 +46,13 @@ SIGNATURES = {
     'pifu_reserve': (_i32, [_p, _i64]),
     'pifu_workspace_bytes': (_i64, [_p]),
     'pifu_set_workspace_limit': (_i32, [_p, _i64]),
+    'pifu_arena_bytes': (_i64, [_p, _i32]),
+    'pifu_set_host_threads': (_i32, [_i32]),
+    'pifu_comm_unique_id': (_i32, [_p]),
+    'pifu_comm_create': (_i32, [_i32, _i32, _i32, _p, C.POINTER(_p)]),
+    'pifu_comm_destroy': (_i32, [_p]),
+    'pifu_allgather_f32': (_i32, [_p, _p, _p, _i64, _p]),
+    'pifu_allgather_bytes': (_i32, [_p, _p, _p, _i64, _p]),
     'pifu_mlp_define': (_i32, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32]),
     'pifu_mlp_set_layer': (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'pifu_set_precision': (_i32, [_p, _i32]),

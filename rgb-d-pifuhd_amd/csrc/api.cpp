@@ -32,7 +32,7 @@ void pifu_set_error(const char *fmt, ...)
 extern "C" const char *pifu_last_error(void) { return g_err; }
 extern "C" int pifu_abi_version(void) { return PIFU_ABI_VERSION; }
 
-int pifu_ensure(DevBuf &b, size_t bytes)
+int pifu_ensure(DevBuf &b, size_t bytes, bool exact)
 {
     if (bytes <= b.bytes) return PIFU_OK;
     if (b.p) {
@@ -41,7 +41,7 @@ int pifu_ensure(DevBuf &b, size_t bytes)
         b.p = nullptr;
         b.bytes = 0;
     }
-    const size_t want = bytes + bytes / 8;
+    const size_t want = exact ? bytes : bytes + bytes / 8;
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -148,6 +148,8 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     if (ctx->debug_buf) (void)hipFree(ctx->debug_buf);
 #endif
+    if (ctx->pix.built) (void)hipEventDestroy(ctx->pix.built);
+    for (auto &kv : ctx->pix.readers) (void)hipEventDestroy(kv.second);
     if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
@@ -239,6 +241,13 @@ extern "C" int64_t pifu_workspace_bytes(pifu_ctx *ctx)
 {
     return ctx ? (int64_t)(ctx->arena.bytes + ctx->mc_arena.bytes + ctx->oct_arena.bytes + ctx->misc.bytes + ctx->col_arena.bytes +
                            ctx->pix_arena.bytes) : 0;
+}
+
+extern "C" int64_t pifu_arena_bytes(pifu_ctx *ctx, int which)
+{
+    if (!ctx) return 0;
+    const DevBuf *bufs[] = {&ctx->arena, &ctx->mc_arena, &ctx->oct_arena, &ctx->col_arena, &ctx->pix_arena, &ctx->misc};
+    return which >= 0 && which < 6 ? (int64_t)bufs[which]->bytes : 0;
 }
 
 // 0 = exact fp32 MFMA (default); 1 = bf16 x 3 split precision (~1e-5 on the occupancy); 2 = fp16 x 3 (~1e-6)
@@ -473,9 +482,11 @@ namespace {
 
 constexpr int64_t OBJ_BLOCK = 16384;        // lines per block of the writer
 
+std::atomic<int> g_host_threads{0};          // pifu_set_host_threads: 0 = the machine's
+
 inline int obj_threads(int64_t nblocks)
 {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = g_host_threads.load() > 0 ? (unsigned)g_host_threads.load() : std::thread::hardware_concurrency();
 #ifdef PIFU_LAB     // tools/obj_bench.py: writer threads as a parameter
     if (const char *v = getenv("PIFU_OBJ_THREADS")) hw = (unsigned)atoi(v);
 #endif
@@ -658,6 +669,13 @@ struct ObjWriter {
 };
 
 }  // namespace
+
+extern "C" int pifu_set_host_threads(int n)
+{
+    PIFU_REQUIRE(n >= 0, PIFU_ERR_INVALID, "pifu_set_host_threads: negative thread count");
+    g_host_threads.store(n);
+    return PIFU_OK;
+}
 
 extern "C" int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride,
                               void **writer)

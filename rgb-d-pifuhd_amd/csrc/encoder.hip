@@ -706,15 +706,26 @@ struct EncState {
     bool coarse_pending = false;                 // the deferred coarse hourglass has been issued and not yet joined
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
+    pifu_ctx *ctx = nullptr;                     // owner (pifu_profile_*: algorithmic FLOPs of the convolutions, slot PIFU_PROF_ENC)
     std::string err;
 };
+
+// books one convolution's ALGORITHMIC work (2 * output pixels * Cout * Cin * taps; padding of K / Cout not counted) while
+// profiling is on; the launches run on up to three concurrent lanes, so they are counted, not timed (the pass is timed whole)
+inline void book_conv(EncState &S, double flops)
+{
+    if (S.ctx && S.ctx->prof_on) {
+        S.ctx->prof[PIFU_PROF_ENC].work += flops;
+        S.ctx->prof[PIFU_PROF_ENC].launches += 1;
+    }
+}
 
 std::map<pifu_ctx *, EncState *> g_states;
 
 EncState &state_of(pifu_ctx *ctx)
 {
     auto it = g_states.find(ctx);
-    if (it == g_states.end()) it = g_states.emplace(ctx, new EncState()).first;
+    if (it == g_states.end()) { it = g_states.emplace(ctx, new EncState()).first; it->second->ctx = ctx; }
     return *it->second;
 }
 
@@ -1009,6 +1020,7 @@ void conv2d(EncState &S, const std::string &wname, const std::string &bname, con
         if (residual) { a.R = residual->p; a.ldr = residual->ld; }
         a.os = 1; a.oy0 = 0; a.ox0 = 0; a.Wout = out.W;
         launch_conv_dma(S, a, tn, &out);
+        book_conv(S, 2.0 * nrows * co * (double)ci * g.k * g.k);
     }
 }
 
@@ -1064,6 +1076,7 @@ void conv_transpose2d(EncState &S, const std::string &wname, const std::string &
         } else {
             for (int c = 0; c < 4; ++c) launch_conv_dma(S, four.a[c], tn, &out, c, 4);
         }
+        book_conv(S, 2.0 * x.H * x.W * (double)co * ci * 9.0);       // every input pixel meets each of the 3 x 3 taps once
     }
 }
 
@@ -1216,6 +1229,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     if (x.C % 16 != 0) throw Fail{"k_conv7_to3_tanh needs a multiple of 16 input channels"};
     hipLaunchKernelGGL(k_conv7_to3_tanh, dim3((unsigned)(((x.W + 15) / 16) * ((x.H + 15) / 16))), dim3(256), 0, S.cur->st, (const float *)x.p,
                        x.ld, x.H, x.W, x.C, act.scale, act.shift, (const float *)S.dev[key], bias, dst_nchw);
+    book_conv(S, 2.0 * x.H * x.W * 3.0 * (double)w.shape[1] * 49.0);
 }
 
 Tensor pack_input(EncState &S, const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn)

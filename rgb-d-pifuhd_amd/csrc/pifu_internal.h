@@ -34,7 +34,7 @@ constexpr int PIFU_BN = 128;   // output channels per block tile
 constexpr int PIFU_BK = 32;    // K step; every K segment is padded to a multiple of it
 constexpr int PIFU_MAX_LAYERS = 8;
 constexpr int PIFU_MAX_WIDTH = 8192;  // widest MLP layer / input supported
-constexpr int PIFU_PROF_SLOTS = 3;    // PIFU_PROF_GEMM, PIFU_PROF_SAMPLER, PIFU_PROF_MC
+constexpr int PIFU_PROF_SLOTS = 4;    // PIFU_PROF_GEMM, PIFU_PROF_SAMPLER, PIFU_PROF_MC, PIFU_PROF_ENC
 
 static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
@@ -125,7 +125,13 @@ struct pifu_ctx {
     // pixel tables of explicit point lists (query.hip "Pixel tables"): G = W_feat * F over the pixels of the coarse map
     int pix_mode = 1;                     // pifu_set_pixel_tables: 0 off, 1 from PIFU_PIXEL_TABLE_MIN_POINTS points on, 2 always
     DevBuf pix_arena;
-    struct PixState { bool valid = false; const float *feat = nullptr; int H = 0, W = 0, C = 0, precision = 0, ldg = 0; } pix;
+    // `built` orders every reader's stream behind the table's construction; `readers` holds one event per stream that has
+    // blended from the table (recorded after its last expand kernel) - a rebuild in place waits for all of them
+    struct PixState {
+        bool valid = false; const float *feat = nullptr; int H = 0, W = 0, C = 0, precision = 0, ldg = 0;
+        hipEvent_t built = nullptr;
+        std::map<hipStream_t, hipEvent_t> readers;
+    } pix;
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
@@ -160,7 +166,8 @@ int pifu_prof_begin(pifu_ctx *ctx, int slot, hipStream_t st, hipEvent_t *stop);
 // records the stop event and books the launch's algorithmic work
 int pifu_prof_end(pifu_ctx *ctx, int slot, hipEvent_t stop, double work, hipStream_t st);
 
-int pifu_ensure(DevBuf &b, size_t bytes);   // grow-only hipMalloc (synchronises when it grows)
+// grow-only hipMalloc (synchronises when it grows); `exact`: no slack on top of `bytes` (arenas with a caller-set bound)
+int pifu_ensure(DevBuf &b, size_t bytes, bool exact = false);
 // encoder.hip: make `st` wait for a coarse hourglass that pifu_filter_coarse(PIFU_ENC_DEFER_JOIN) left running
 int pifu_enc_join(pifu_ctx *ctx, hipStream_t st);
 

@@ -1695,9 +1695,14 @@ static int build_pixel_table(pifu_ctx *ctx, hipStream_t st)
     const Mlp &m = ctx->mlp[0];
     const FeatMap &f = ctx->feat[0];
     pifu_ctx::PixState &px = ctx->pix;
+    if (!px.built) PIFU_HIP(hipEventCreateWithFlags(&px.built, hipEventDisableTiming));
     if (px.valid && px.feat == f.nhwc && px.H == f.H && px.W == f.W && px.C == f.C && px.precision == ctx->precision &&
-        px.ldg == m.col_rows)
+        px.ldg == m.col_rows) {
+        PIFU_HIP(hipStreamWaitEvent(st, px.built, 0));      // another stream may have enqueued the construction a moment ago
         return PIFU_OK;
+    }
+    // rebuilt in place: every stream that blended from the previous table must have finished with it
+    for (auto &kv : px.readers) PIFU_HIP(hipStreamWaitEvent(st, kv.second, 0));
     const int64_t hw = (int64_t)f.H * f.W, hw_pad = round_up(hw, BM);
     const size_t gbytes = ((size_t)hw_pad * m.col_rows * sizeof(float) + 255) & ~(size_t)255;
     const size_t fbytes = hw != hw_pad ? (size_t)hw_pad * f.Cpad * sizeof(float) : 0;     // row tiles must not read past the map
@@ -1723,6 +1728,7 @@ static int build_pixel_table(pifu_ctx *ctx, hipStream_t st)
     for (int i = 0; i < m.nlayers; ++i) if (m.layer[i].cin_feat) real_rows += m.layer[i].cout;
     rc = run_gemm(ctx, a, 2.0 * hw * real_rows * (double)(m.dims[0] - 1), st);
     if (rc) return rc;
+    PIFU_HIP(hipEventRecord(px.built, st));
     px.valid = true; px.feat = f.nhwc; px.H = f.H; px.W = f.W; px.C = f.C; px.precision = ctx->precision; px.ldg = m.col_rows;
     return PIFU_OK;
 }
@@ -1929,7 +1935,7 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     const int upto_c = want_coarse ? mc.nlayers : mc.merge_layer + 1;
     // (also lattice sources whose calibration rules out column sharing: x or y depends on k)
     bool pixmode = !colmode && !(flags & PIFU_Q_NO_COLUMN_SHARING) && ctx->pix_mode != 0 &&
-                   (ctx->pix_mode == 2 || n >= PIFU_PIXEL_TABLE_MIN_POINTS) && mc.nlayers >= 2 && !mc.res[0] &&
+                   (ctx->pix_mode == 2 || (n >= PIFU_PIXEL_TABLE_MIN_POINTS && n >= (int64_t)ctx->feat[0].H * ctx->feat[0].W)) && mc.nlayers >= 2 && !mc.res[0] &&
                    ctx->feat[0].C % BK == 0 && ctx->feat[0].Cpad == ctx->feat[0].C;
 #ifdef PIFU_LAB     // the lab kernels (tools/lab) do not know GemmArgs::qrel
     pixmode = false;
@@ -1952,8 +1958,10 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     Plan probe;
     for (;;) {
         probe = carve(ctx, nullptr, rows_cap, batch_chunks, fine, normal_pts, walk_ok, pixmode ? pxm.nS * BN : -1);
-        const bool over = ctx->ws_limit > 0 && probe.bytes > (size_t)ctx->ws_limit && probe.bytes > ctx->arena.bytes;
-        rc = over ? PIFU_ERR_NOMEM : pifu_ensure(ctx->arena, probe.bytes);
+        // a bound is a bound: an arena that outgrew it (allocated before the bound was set: pifu_set_workspace_limit releases
+        // those) is not reused, and the allocation carries no slack
+        const bool over = ctx->ws_limit > 0 && probe.bytes > (size_t)ctx->ws_limit;
+        rc = over ? PIFU_ERR_NOMEM : pifu_ensure(ctx->arena, probe.bytes, ctx->ws_limit > 0);
         if (rc != PIFU_ERR_NOMEM || batch_chunks <= 1) break;
         batch_chunks = (batch_chunks + 1) / 2;
         rows_cap = batch_chunks * P;
@@ -2081,6 +2089,11 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                               fine_out ? fine_out + pt0 : nullptr, ctx->mlp[1].nlayers, st);
             if (rc != PIFU_OK) return rc;
         }
+    }
+    if (pixmode) {      // this stream has read the pixel table up to here: a rebuild on another stream waits for it
+        hipEvent_t &ev = ctx->pix.readers[st];
+        if (!ev) PIFU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        PIFU_HIP(hipEventRecord(ev, st));
     }
     PIFU_HIP(hipGetLastError());
     return PIFU_OK;

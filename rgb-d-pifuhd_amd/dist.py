@@ -38,6 +38,62 @@ def collective_active():
     return dist.get_world_size() > 1 or ALWAYS_COLLECTIVE
 
 
+# ---- the collective itself ---------------------------------------------------------------------------------------------------
+# Default: torch.distributed's all_gather_into_tensor (backend nccl = RCCL on ROCm, gloo in the CPU tests).
+# `use_native_comm()` switches the device-tensor all-gathers to the library's own RCCL communicator (`pifu_comm_*`,
+# `pifu_allgather_*` of include/pifuhd_hip.h) - the same collective as a binding without torch.distributed would issue it;
+# torch.distributed is then only the side channel that hands rank 0's communicator id to the other ranks.
+_native = None
+
+
+def use_native_comm(device):
+    """Create the library's RCCL communicator over the ranks of the initialised process group (collective) and route the
+    device all-gathers of this module through it.  Returns the communicator handle."""
+    import torch.distributed as dist
+    from . import _lib
+    global _native
+    rank, ws = world()
+    dev = torch.device(device)
+    ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        _lib.call('pifu_comm_unique_id', buf)
+        ident = torch.tensor(list(buf), dtype=torch.uint8)
+    if ws > 1:
+        carrier = ident.to(dev) if dist.get_backend() == 'nccl' else ident
+        dist.broadcast(carrier, src=0)
+        ident = carrier.cpu()
+    raw = (C.c_uint8 * _lib.COMM_ID_BYTES)(*ident.tolist())
+    handle = C.c_void_p()
+    _lib.call('pifu_comm_create', dev.index or 0, rank, ws, raw, C.byref(handle))
+    _native = {'h': handle, 'device': dev}
+    return handle
+
+
+def release_native_comm():
+    from . import _lib
+    global _native
+    if _native is not None:
+        _lib.call('pifu_comm_destroy', _native['h'])
+        _native = None
+
+
+def _all_gather(full, local, group=None):
+    """full [ws * n, ...] <- every rank's local [n, ...] (contiguous tensors of one dtype)."""
+    import torch.distributed as dist
+    if _native is not None and full.is_cuda and full.device == _native['device']:
+        from . import _lib
+        from .nets import _ptr, _stream_ptr
+        assert full.is_contiguous() and local.is_contiguous() and full.numel() == world()[1] * local.numel()
+        if full.dtype == torch.float32:
+            _lib.call('pifu_allgather_f32', _native['h'], _ptr(local), _ptr(full), local.numel(), _stream_ptr(full.device))
+        else:
+            _lib.call('pifu_allgather_bytes', _native['h'], _ptr(local), _ptr(full), local.numel() * local.element_size(),
+                      _stream_ptr(full.device))
+        return
+    dist.all_gather_into_tensor(full, local, group=group)
+
+
 def shard_chunks(total_points: int, chunk: int, world_size: int, rank: int):
     """Contiguous range of whole chunks for `rank`: returns (first_point, n_points, chunks_per_rank).
     Every rank gets `chunks_per_rank` chunks except the tail (possibly fewer or none)."""
@@ -66,7 +122,7 @@ def sharded_eval(total_points: int, chunk: int, eval_fn, device, group=None):
     if count > 0:
         local[:count] = eval_fn(first, count)
     full = torch.empty(ws * slot, device=device, dtype=torch.float32)
-    dist.all_gather_into_tensor(full, local, group=group)
+    _timed(lambda: _all_gather(full, local, group), full.numel() * 4, device)
     return full[:total_points]
 
 
@@ -139,54 +195,88 @@ def shard_range(n_items: int, world_size: int, rank: int):
     return i0, min(i0 + per, n_items), per
 
 
-def sharded_calls(spans, call_fn, width, device, group=None):
-    """Shard a list of independent calls (each one GroupNorm batch, e.g. the 50 000-vertex `calc_normal`
-    calls of `gen_mesh`, `reconstruction.py:58-70`) across ranks by contiguous call ranges.
-
-    spans: list of (left, right) row ranges, ascending and disjoint; call_fn(left, right) -> float32 tensor
-    [right-left, width] on `device`.  Returns float32 [spans[-1][1], width] (rows outside every span are 0),
-    identical on every rank after ONE all-gather."""
-    import torch.distributed as dist
-    rank, ws = world()
-    n_rows = spans[-1][1] if spans else 0
-    out = torch.zeros(n_rows, width, device=device, dtype=torch.float32)
-    if not collective_active():
-        for (l, r) in spans:
-            out[l:r] = call_fn(l, r)
-        return out
-    i0, i1, per = shard_range(len(spans), ws, rank)
-    slot_rows = max(max((r - l) for (l, r) in spans), 1) * per
-    local = torch.zeros(slot_rows, width, device=device, dtype=torch.float32)
-    row = 0
-    for (l, r) in spans[i0:i1]:
-        local[row:row + (r - l)] = call_fn(l, r)
-        row += r - l
-    full = torch.empty(ws * slot_rows, width, device=device, dtype=torch.float32)
-    dist.all_gather_into_tensor(full, local, group=group)
-    for rk in range(ws):
-        j0, j1, _ = shard_range(len(spans), ws, rk)
-        row = rk * slot_rows
-        for (l, r) in spans[j0:j1]:
-            out[l:r] = full[row:row + (r - l)]
-            row += r - l
+def colour_rounds(n_spans, ws, per_call_cap=10, target_rounds=4):
+    """The colour loop of `gen_mesh` (`reconstruction.py:58-70`) as rounds: [(first_span, spans_per_rank)].  In a round,
+    rank r computes the `spans_per_rank` consecutive calc_normal calls that start at `first_span + r * spans_per_rank`, so
+    the ranks' results laid side by side ARE the colour rows of spans [first_span, first_span + ws * spans_per_rank) in
+    vertex order (every span but the very last has exactly `interval` rows): one all-gather per round extends the PREFIX
+    of finished colours, which is what the OBJ writer's `ready(upto)` takes.  Every rank ends with ceil(n_spans / ws)
+    calls or fewer; a round is at most `per_call_cap` calls per rank (ten 50 000-vertex calls = 2.0 M point rows = one
+    batch of launches of the workspace) and there are `target_rounds` rounds where the mesh allows, so the last exchange +
+    file block is a quarter of the loop at most.  One rank: plain groups of at most ten calls."""
+    per_rank = -(-n_spans // ws)
+    rounds = max(min(target_rounds, per_rank), -(-per_rank // per_call_cap), 1)
+    out, base = [], 0
+    for k in range(rounds):
+        m = per_rank // rounds + (1 if k < per_rank % rounds else 0)
+        if base >= n_spans or m == 0:
+            break
+        out.append((base, m))
+        base += ws * m
     return out
 
 
-def gather_runs(runs, mine, run_fn, width, device, group=None):
-    """`runs`: one contiguous row range (left, right) per rank that has work, ascending; `mine`: this rank's run (list of
-    0 or 1 entries); run_fn(left, right) -> float32 [right-left, width].  One all-gather; returns [runs[-1][1], width]."""
+def round_rows(spans, base, m, ws, rank, interval):
+    """One round of `colour_rounds`: (this rank's vertex rows (left, right) or None when it has no call in the round, the
+    round's vertex rows (L, R) over all ranks, rows per rank slot of the exchange buffer)."""
+    lo_s, hi_s = base + rank * m, min(base + (rank + 1) * m, len(spans))
+    mine = (spans[lo_s][0], spans[hi_s - 1][1]) if hi_s > lo_s else None
+    return mine, (spans[base][0], spans[min(base + ws * m, len(spans)) - 1][1]), m * interval
+
+
+def all_gather_rows(full, local, device=None, group=None):
+    """One all-gather of equal-sized row blocks: `full` [ws * rows, ...] receives rank r's `local` [rows, ...] at rows
+    [r * rows, (r + 1) * rows).  The colour loop of the sharded `gen_mesh` calls it once per round, from its copy stream
+    (RCCL joins the stream that is current at the call, so the compute stream is not held up)."""
     import torch.distributed as dist
-    rank, ws = world()
-    n_rows = runs[-1][1] if runs else 0
-    slot_rows = max(max((r - l) for (l, r) in runs), 1) if runs else 1
-    local = torch.zeros(slot_rows, width, device=device, dtype=torch.float32)
-    for (l, r) in mine:
-        local[:r - l] = run_fn(l, r)
-    full = torch.empty(ws * slot_rows, width, device=device, dtype=torch.float32)
-    dist.all_gather_into_tensor(full, local, group=group)
-    out = torch.zeros(n_rows, width, device=device, dtype=torch.float32)
-    for rk, (l, r) in enumerate(runs):          # ranks with work are the first len(runs) ranks (shard_range is monotone)
-        out[l:r] = full[rk * slot_rows: rk * slot_rows + (r - l)]
+    _timed(lambda: _all_gather(full, local, group), full.numel() * full.element_size(), full.device)
+    return full
+
+
+# ---- what the collectives of one sharded call cost (bench.py puts it into the N > 1 line) --------------------------------
+_stats = None
+
+
+def stats_begin():
+    """Start recording: every collective of the sharded entry points is bracketed by events on the stream it is issued
+    from and its gathered bytes are counted, until `stats_end()`."""
+    global _stats
+    _stats = {'events': [], 'bytes': 0, 'calls': 0, 'host_s': 0.0}
+
+
+def stats_end():
+    """{'collectives': n, 'collective_bytes': gathered bytes per rank, 'collective_s': time between the events around the
+    collectives (device tensors; it includes waiting for the slowest rank), 'collective_host_s': host time inside the
+    calls}.  Synchronises the events."""
+    global _stats
+    st, _stats = _stats, None
+    if st is None:
+        return {}
+    ms = 0.0
+    for (e0, e1) in st['events']:
+        e1.synchronize()
+        ms += e0.elapsed_time(e1)
+    return {'collectives': st['calls'], 'collective_bytes': st['bytes'], 'collective_s': round(ms * 1e-3, 5),
+            'collective_host_s': round(st['host_s'], 5)}
+
+
+def _timed(fn, nbytes, device):
+    import time
+    if _stats is None:
+        return fn()
+    dev = torch.device(device)
+    ev = None
+    if dev.type == 'cuda':
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(dev))
+    h0 = time.perf_counter()
+    out = fn()
+    _stats['host_s'] += time.perf_counter() - h0
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(dev))
+        _stats['events'].append(ev)
+    _stats['bytes'] += int(nbytes)
+    _stats['calls'] += 1
     return out
 
 
@@ -219,7 +309,7 @@ def marching_cubes_sharded(ctx, volume, level, group=None):
     # float64 carries the counts exactly (< 2^31 vertices by the int32 face indices) next to the range
     stat = torch.tensor([nv, nf, lo, hi], device=dev, dtype=torch.float64)
     stats = torch.empty(ws * 4, device=dev, dtype=torch.float64)      # gathered tensors are concatenated along axis 0
-    dist.all_gather_into_tensor(stats, stat, group=group)
+    _timed(lambda: _all_gather(stats, stat, group), stats.numel() * 8, dev)
     stats = stats.view(ws, 4).cpu()
     nvs = [int(x) for x in stats[:, 0]]
     nfs = [int(x) for x in stats[:, 1]]
@@ -232,7 +322,7 @@ def marching_cubes_sharded(ctx, volume, level, group=None):
         verts = torch.empty(0, 3, device=dev, dtype=torch.float32)
         halo = torch.zeros(2, n1, n2, device=dev, dtype=torch.int32)
     halos = torch.empty(ws * 2, n1, n2, device=dev, dtype=torch.int32)
-    dist.all_gather_into_tensor(halos, halo, group=group)
+    _timed(lambda: _all_gather(halos, halo, group), halos.numel() * 4, dev)
     halos = halos.view(ws, 2, n1, n2)
     # slabs without cells are the last ranks (slab_planes deals the cell layers out from rank 0), so the slab below is rank - 1
     faces = step.faces(halos[rank - 1] if rank > 0 else None) if step else torch.empty(0, 3, device=dev, dtype=torch.int32)
@@ -243,7 +333,7 @@ def marching_cubes_sharded(ctx, volume, level, group=None):
     pad_f[:nf] = faces
     all_v = torch.empty(ws * cap_v, 3, device=dev, dtype=torch.float32)
     all_f = torch.empty(ws * cap_f, 3, device=dev, dtype=torch.int32)
-    dist.all_gather_into_tensor(all_v, pad_v, group=group)
-    dist.all_gather_into_tensor(all_f, pad_f, group=group)
+    _timed(lambda: _all_gather(all_v, pad_v, group), all_v.numel() * 4, dev)
+    _timed(lambda: _all_gather(all_f, pad_f, group), all_f.numel() * 4, dev)
     all_v, all_f = all_v.view(ws, cap_v, 3), all_f.view(ws, cap_f, 3)
     return (torch.cat([all_v[r, :nvs[r]] for r in range(ws)]), torch.cat([all_f[r, :nfs[r]] for r in range(ws)]))

@@ -174,7 +174,7 @@ def marching_cubes_slabs(ctx, volume, level, nslabs):
     return torch.cat(verts), torch.cat(faces)
 
 
-def transform_verts(ctx, verts_d, trans_mat, defer_host=False):
+def transform_verts(ctx, verts_d, trans_mat, defer_host=False, host=True):
     """`(trans_mat[:3, :3] @ verts.T + trans_mat[:3, 3:4]).T` in float64 (`mesh_util.py:87-89`) on the device
     (`pifu_transform_verts`).  Returns (host float64 [V, 3], the same array as a device tensor).  The kernel evaluates each
     coordinate as the FMA chain `fma(m2, z, fma(m1, y, m0 * x))` followed by the addition of the translation - the order in
@@ -186,15 +186,17 @@ def transform_verts(ctx, verts_d, trans_mat, defer_host=False):
     out_d = torch.empty(n, 3, device=verts_d.device, dtype=torch.float64)
     _lib.call('pifu_transform_verts', ctx.h, _ptr(verts_d), n, rows.ctypes.data_as(C.c_void_p), _ptr(out_d),
               _stream_ptr(ctx.device))
+    if not host:
+        return None, out_d
     if defer_host:
-        host, ev = to_host_async(out_d)
-        return host, out_d, ev
+        host_arr, ev = to_host_async(out_d)
+        return host_arr, out_d, ev
     return to_host(out_d), out_d
 
 
 def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5, use_octree=False,
                    num_samples=10000, transform=None, return_sdf=False, sharded=False, return_device_verts=False,
-                   _defer_host=False):
+                   _defer_host=False, _host_result=True):
     """`reconstruction` (`mesh_util.py:40-96`): returns (verts float64 [V,3], faces int32 [F,3], normals,
     values) or -1.  Like the reference, `b_min`, `b_max` and `transform` are ignored (the box is always
     [-1,1]^3 before calib^-1, SURVEY C-5).  `normals` / `values` (discarded by gen_mesh) are returned empty.
@@ -204,7 +206,8 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     `return_device_verts=True` appends the float64 vertices as a device tensor (the colour loop of `gen_mesh` continues
     from it without a host round trip).  `_defer_host=True` (gen_mesh): the vertex and face arrays cross to the host on
     the copy stream while the caller goes on issuing work; a `HostCopies` is appended to the result, and the arrays' CONTENTS
-    are valid only after its `wait_faces()` / `wait_verts()`."""
+    are valid only after its `wait_faces()` / `wait_verts()`.  `_host_result=False` (a rank of a sharded gen_mesh that
+    returns nothing): no host copies at all - `verts` and `faces` come back as None, the device vertices are still there."""
     ctx = _ctx_of(net)
     from . import dist as pdist
     if sharded and pdist.collective_active():
@@ -230,8 +233,12 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
         print('error cannot marching cubes')                                             # mesh_util.py:94-96
         return -1
     pending = HostCopies()
-    if _defer_host:
+    pending.n_verts, pending.n_faces = int(verts_d.shape[0]), int(faces_d.shape[0])
+    if not _host_result:
+        faces = None
+    elif _defer_host:
         faces, pending.faces = to_host_async(faces_d)
+        pending.keep.append(faces)
     else:
         faces = to_host(faces_d)
     _, calib_inv = calib_pair(calib_tensor)
@@ -239,11 +246,14 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     mat[0, 0] = mat[1, 1] = mat[2, 2] = 2.0 / resolution
     mat[0:3, 3] = -1.0
     trans_mat = np.matmul(calib_inv, mat)
-    if _defer_host:
+    if not _host_result:
+        verts, verts_dev = transform_verts(ctx, verts_d, trans_mat, host=False)
+    elif _defer_host:
         verts, verts_dev, pending.verts = transform_verts(ctx, verts_d, trans_mat, defer_host=True)   # mesh_util.py:87-89
+        pending.keep.append(verts)
     else:
         verts, verts_dev = transform_verts(ctx, verts_d, trans_mat)
-    if np.linalg.det(trans_mat[:3, :3]) < 0.0:
+    if faces is not None and np.linalg.det(trans_mat[:3, :3]) < 0.0:
         faces = faces[:, ::-1]                                                       # mesh_util.py:91-92
     normals = np.zeros((0, 3), np.float32)
     values = np.zeros((0,), np.float32)
@@ -256,10 +266,20 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
 
 
 class HostCopies:
-    """The device-to-host copies `reconstruction(_defer_host=True)` left running on the copy stream."""
+    """The device-to-host copies `reconstruction(_defer_host=True)` left running on the copy stream.  It holds the arrays
+    themselves until they have been waited for: they are views of pinned slabs that are handed out again once the array
+    is gone, so a caller that fails between `reconstruction()` and the waits must not be able to free a slab a copy is
+    still writing to (`wait_all()` in its `finally`)."""
 
     def __init__(self):
         self.faces = self.verts = None
+        self.keep = []
+        self.n_verts = self.n_faces = 0
+
+    def wait_all(self):
+        self.wait_faces()
+        self.wait_verts()
+        self.keep = []
 
     def wait_faces(self):
         if self.faces is not None:
@@ -349,9 +369,13 @@ def _to_host(t, issue=True):
             slot = s
             break
     if slot is None:
-        for s in list(_slabs):                         # a free slab that is too small makes room for one that fits
-            if s[1]() is None and _pool_bytes() + want > POOL_MAX_BYTES:
-                _drop_slab(s)
+        # no free slab fits: free slabs that are too small make room for one that does - smallest first, as many as the byte
+        # cap or the slab count asks for (subjects of growing size would otherwise fill the pool with slabs that fit nothing
+        # and leave every later result on the pageable, synchronous path for good)
+        for s in sorted((s for s in _slabs if s[1]() is None), key=lambda s: s[0].numel()):
+            if len(_slabs) < POOL_MAX_SLABS and _pool_bytes() + want <= POOL_MAX_BYTES:
+                break
+            _drop_slab(s)
         if len(_slabs) >= POOL_MAX_SLABS or _pool_bytes() + want > POOL_MAX_BYTES:
             return t.cpu().numpy(), None
         slot = [torch.empty(want, dtype=torch.uint8, pin_memory=True), lambda: None]

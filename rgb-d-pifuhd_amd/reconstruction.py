@@ -21,6 +21,18 @@ from .mesh_util import ObjFile, copy_stream, pinned_flat as mesh_util_pinned, pi
 from .nets import index
 
 
+HOST_THREADS = 0          # set_host_threads(): 0 = no bound of this package's own (PNG: 8 bands, OBJ writer: the machine's, <= 32)
+
+
+def set_host_threads(n):
+    """Bound the host worker threads one gen_mesh call starts (OBJ formatting / writing threads of the library, PNG deflate
+    bands): for several processes on one host - one per GPU - `os.cpu_count() // ranks`.  0 = default."""
+    global HOST_THREADS
+    from . import _lib
+    HOST_THREADS = max(int(n), 0)
+    _lib.call('pifu_set_host_threads', HOST_THREADS)
+
+
 def write_png(path, rgb, level=1, bands=8):
     """8-bit RGB PNG of `rgb` (uint8 [H, W, 3]) with the deflate stream cut into `bands` row bands that are compressed on
     threads (zlib releases the GIL): every band is a raw deflate stream of its own ending on a byte boundary (sync flush;
@@ -35,6 +47,8 @@ def write_png(path, rgb, level=1, bands=8):
     raw = np.zeros((h, 1 + 3 * w), np.uint8)               # filter byte 0 + the row
     raw[:, 1:] = rgb.reshape(h, 3 * w)
     bands = max(1, min(int(bands), h, raw.size // 65536))      # a thread per 64 KB at least
+    if HOST_THREADS:
+        bands = min(bands, HOST_THREADS)
     cuts = [h * k // bands for k in range(bands + 1)]
 
     def deflate(k):
@@ -84,6 +98,15 @@ def _save_debug_png(path, image_tensor_global, background=False):
     return th
 
 
+def _prof_read(net, which):
+    """(ms, launches, work) of one profiling slot of the net's context, not reset (`pifu_profile_read`; synchronises)."""
+    import ctypes as C
+    from . import _lib
+    ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+    _lib.call('pifu_profile_read', net._ctx.h, which, C.byref(ms), C.byref(n), C.byref(w), 0)
+    return ms.value, n.value, w.value
+
+
 def _normal_spans(n_verts, interval=50000):
     """The slices of the reference's colour loop (`reconstruction.py:58-70`): `interval`-vertex calls, the last
     one ending at -1, so the last vertex is never coloured (SURVEY C-6)."""
@@ -108,14 +131,6 @@ def _upload_beside(t, dev):
     cur.wait_stream(side)
     out.record_stream(cur)
     return out
-
-
-def _span_groups(spans, per=10):
-    """Vertex ranges (left, right) made of `per` whole consecutive spans each: the units of the colour-loop pipeline.  Ten
-    50 000-vertex calc_normal calls are 2.0 M point rows: one batch of launches of a 2 M-row workspace, two of the default
-    1 M-row one, in both cases without a small left-over batch."""
-    per = max(int(per), 1)
-    return [(spans[i][0], spans[min(i + per, len(spans)) - 1][1]) for i in range(0, len(spans), per)]
 
 
 class _Subject:
@@ -143,17 +158,31 @@ class _Subject:
 
 
 def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, components=False, timings=None,
-             sharded=False, _pipeline=True, _defer_host=True):
-    """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.
+             sharded=False, result_on='rank0', _pipeline=True, _defer_host=True):
+    """Generate the mesh of one subject.  `data` is the dict of `readData.py:106-116`.  Writes `<save_path>` and the debug
+    PNG like the reference (`reconstruction.py:25-72`) and returns (verts float64 [V,3], faces int32 [F,3], colours float64
+    [V,3]) - the arrays the reference hands to its writer.
 
-    `sharded=True` (not in the reference, which is single-device): every rank of the initialised
-    `torch.distributed` group calls gen_mesh with the SAME data; grid evaluation shards by whole chunks and the
-    colour loop by whole calc_normal calls (`pifuhd_amd.dist`), every rank returns the identical mesh and
-    rank 0 writes the files."""
+    `sharded=True` (not in the reference, which is single-device): every rank of the initialised `torch.distributed` group
+    calls gen_mesh with the SAME data; grid evaluation shards by whole chunks (`pifuhd_amd.dist`), the colour loop by whole
+    calc_normal calls dealt out in rounds (`dist.colour_rounds`), rank 0 writes the files - streaming, as the single-GPU
+    pipeline does.  `result_on='rank0'` (default): the other ranks copy nothing to the host and return None;
+    `result_on='all'`: every rank returns the identical arrays."""
     from . import dist as pdist
     dev = net.device
     rank, ws = pdist.world() if sharded else (0, 1)
     exchange = sharded and pdist.collective_active()
+    if result_on not in ('rank0', 'all'):
+        raise ValueError("result_on must be 'rank0' or 'all'")
+    wants_result = rank == 0 or result_on == 'all' or not exchange
+    if exchange and timings is not None:
+        pdist.stats_begin()
+    # timings['profile_phases'] = True (bench.py, with pifu_profile_enable on): the executed GEMM FLOPs and the summed GEMM
+    # kernel time are read at the phase boundaries - each read synchronises the device, so such a run is for the split, not
+    # for the clock
+    phases = bool(timings is not None and timings.pop('profile_phases', False))
+    from . import _lib as _l
+    p0 = _prof_read(net, _l.PROF_GEMM) if phases else None
 
     def mark():
         if timings is not None:
@@ -168,105 +197,113 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None
     t2 = mark()
 
-    # from here on the PNG thread reads a pinned buffer of this (device, thread): whatever happens below - reconstruction()
-    # returning -1 (TypeError, like the reference), an empty calc_normal slice, a failed collective - the thread is joined
-    # before gen_mesh is left, so the next subject of a recon() loop cannot overwrite pixels that are still being encoded
+    # from here on the PNG thread reads a pinned buffer of this (device, thread), and the result arrays are views of pinned
+    # slabs a copy-stream transfer may still be filling: whatever happens below - reconstruction() returning -1 (TypeError,
+    # like the reference), an empty calc_normal slice, a failed collective - the thread is joined and the copies are waited
+    # for before gen_mesh is left, so the next subject of a recon() loop cannot reuse memory that is still in flight
+    host_copies = None
     try:
-        def spans_check(spans):      # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
-            return any(r == l for (l, r) in spans)
+        # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
+        # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
+        # calc_normal calls go to the GPU in rounds of whole 50 000-vertex calls (the reference's GroupNorm batches,
+        # `reconstruction.py:58-70`, several of them per kernel launch); each round's colours - after one all-gather over
+        # the ranks when the loop is sharded - cross to pinned host memory on the copy stream as soon as they exist, and
+        # the OBJ writer - which has every file offset from the positions alone and has put the face lines in place
+        # already - formats and writes that round's vertex lines on its own threads while the GPU works on the next round.
+        # The 200 MB of vertex / face arrays cross to the host on the copy stream - into the pinned slabs that ARE the
+        # result arrays (`mesh_util.to_host_async`) - while the first round computes: `faces` is waited for once that round
+        # is queued, `verts` before the OBJ layout needs the positions.
+        # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
+        # reference (reconstruction.py:56)
+        verts, faces, _, _, verts_dev, host_copies = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max,
+                                                                    thresh, use_octree=use_octree, num_samples=5000,
+                                                                    sharded=sharded, return_device_verts=True,
+                                                                    _defer_host=True, _host_result=wants_result)
+        if not _defer_host:       # A/B timing: the copies waited for at once, as before round 4
+            host_copies.wait_all()
+        t3 = mark()
+        p3 = _prof_read(net, _l.PROF_GEMM) if phases else None
+        n_verts, n_faces = host_copies.n_verts, host_copies.n_faces
+        spans = _normal_spans(n_verts)
+        if any(r == l for (l, r) in spans):
+            # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
+            raise RuntimeError('calc_normal on an empty vertex slice')
+        verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
+        interval = 50000
 
-        # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
-        # (`reconstruction.py:58-70`), several of them per kernel launch
         def normals_of(left, right):
-            net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=50000)
+            # one chunked call per contiguous run of spans: the same GroupNorm batches as one calc_normal call per span
+            net.calc_normal_chunked(verts_tensor[:, None, :, left:right], calib_tensor[:, None], calib_tensor, interval=interval)
             return (net.nmls.detach()[0] * 0.5 + 0.5).T          # fp32, like the reference's numpy expression
 
-        if exchange:
-            # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly
-            # like the reference (reconstruction.py:56)
-            verts, faces, _, _, verts_dev = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max, thresh,
-                                                           use_octree=use_octree, num_samples=5000, sharded=True,
-                                                           return_device_verts=True)
-            t3 = mark()
-            obj = ObjFile(save_path, faces) if rank == 0 else None   # the face lines are formatted while the colours are computed
-            verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
-            spans = _normal_spans(len(verts))
-            if spans_check(spans):
-                # an empty slice reaches Conv1d in the reference and raises (SURVEY C-6: V % 50000 in {0, 1})
-                raise RuntimeError('calc_normal on an empty vertex slice')
-            i0, i1, _ = pdist.shard_range(len(spans), ws, rank)
-            mine = [(spans[i0][0], spans[i1 - 1][1])] if i1 > i0 else []
-            runs = [(spans[j0][0], spans[j1 - 1][1]) for j0, j1 in
-                    (pdist.shard_range(len(spans), ws, rk)[:2] for rk in range(ws)) if j1 > j0]
-            color32 = pdist.gather_runs(runs, mine, normals_of, 3, dev)
-            color = np.zeros(verts.shape)
-            color[:color32.shape[0]] = color32.cpu().numpy()
-            t4 = mark()
-            if obj is not None:
-                obj.finish(verts, color)                              # save_obj_mesh_with_color (mesh_util.py:189-198)
-        else:
-            # The colour loop as a pipeline.  It continues from the device vertices (cast to fp32 there exactly as
-            # `torch.from_numpy(verts.T).unsqueeze(0).to(device=cuda).float()`, reconstruction.py:57, casts them); the
-            # calc_normal calls go to the GPU in groups of ten whole 50 000-vertex calls; each group's colours cross to pinned
-            # host memory on the copy stream as soon as they exist, and the OBJ writer - which has every file offset from the
-            # positions alone and has put the face lines in place already - formats and writes that group's vertex lines on its
-            # own threads while the GPU works on the next group.
-            # The 200 MB of vertex / face arrays cross to the host on the copy stream - into the pinned slabs that ARE the
-            # result arrays (`mesh_util.to_host_async`: no second host copy, which is what made this a loss in round 3) - while
-            # the first group of the colour loop computes: `faces` is waited for once that group is queued, `verts` before the
-            # OBJ layout needs the positions.  The compute stream used to idle for the 12 ms of these copies.
-            # reconstruction() returns -1 when marching cubes fails; the tuple-unpack then raises TypeError exactly like the
-            # reference (reconstruction.py:56)
-            verts, faces, _, _, verts_dev, host_copies = reconstruction(net, cuda, calib_tensor, res, subj.b_min, subj.b_max,
-                                                                        thresh, use_octree=use_octree, num_samples=5000,
-                                                                        sharded=sharded, return_device_verts=True,
-                                                                        _defer_host=True)
-            if not _defer_host:       # tools/genmesh_ab.py: the copies waited for at once, as before round 4
-                host_copies.wait_faces()
-                host_copies.wait_verts()
-            t3 = mark()
-            obj = None
-            n_verts = len(verts)
-            spans = _normal_spans(n_verts)
-            if spans_check(spans):
-                raise RuntimeError('calc_normal on an empty vertex slice')
-            verts_tensor = verts_dev.T.unsqueeze(0).float().contiguous()
-            n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
+        n_col = spans[-1][1]                                      # the last vertex keeps colour 0 (SURVEY C-6)
+        if wants_result:
             host_col = pinned_rows('colours', n_verts, torch.float32, dev)
             host_col[n_col:].zero_()
             host_np = host_col.numpy()
-            side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
-            done = []
-            # (_pipeline=False - tools/genmesh_ab.py - is the unpipelined form for A/B timing: one group, vertex lines at the end)
-            for (l, r) in _span_groups(spans, 10 if _pipeline else len(spans)):
-                col_d = normals_of(l, r).contiguous()
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    host_col[l:r].copy_(col_d, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                col_d.record_stream(side)
-                done.append((l, r, ev))
-                if obj is None:
-                    host_copies.wait_faces()
-                    obj = ObjFile(save_path, faces)                   # the face lines are formatted while the colours are computed
+        side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
+        wsx = ws if exchange else 1
+        rounds = pdist.colour_rounds(len(spans), wsx) if _pipeline else [(0, -(-len(spans) // wsx))]
+        obj, done = None, []
+        for (base, m) in rounds:
+            mine, (L, R), slot = pdist.round_rows(spans, base, m, wsx, rank, interval)
+            col_d = normals_of(*mine).contiguous() if mine is not None else None
+            if exchange:
+                local = torch.zeros(slot, 3, device=dev, dtype=torch.float32)
+                if col_d is not None:
+                    local[:col_d.shape[0]] = col_d
+                src = torch.empty(ws * slot, 3, device=dev, dtype=torch.float32)
+            else:
+                src = col_d
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                # the exchange is issued from the copy stream: the compute stream goes on with the next round's kernels, the
+                # copy below waits for the collective (RCCL's stream is joined to the CURRENT stream, which is `side` here)
+                if exchange:
+                    pdist.all_gather_rows(src, local, dev)
+                    local.record_stream(side)
+                if wants_result:
+                    host_col[L:R].copy_(src[:R - L], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            src.record_stream(side)
+            done.append((L, R, ev))
+            if obj is None and rank == 0:
+                host_copies.wait_faces()
+                obj = ObjFile(save_path, faces)                   # the face lines are formatted while the colours are computed
+        color = None
+        if wants_result:
             host_copies.wait_verts()
+            color = np.zeros((n_verts, 3))                        # the float64 colour array gen_mesh returns
+        if obj is not None:
             obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
-            color = np.zeros((n_verts, 3))                            # the float64 colour array gen_mesh returns
-            for (l, r, ev) in done:
-                ev.synchronize()
-                obj.ready(r)                                          # this group's vertex lines are formatted and written now
-                color[l:r] = host_np[l:r]                             # while the GPU computes the next group
-            t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
+        for (L, R, ev) in done:
+            ev.synchronize()
+            if obj is not None:
+                obj.ready(R)                                      # this round's vertex lines are formatted and written now
+            if color is not None:
+                color[L:R] = host_np[L:R]                         # while the GPU computes the next round
+        t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
+        if obj is not None:
             obj.finish()
+        if wants_result:
+            host_copies.wait_faces()
     finally:
+        if host_copies is not None:
+            host_copies.wait_all()
         if png_thread is not None:
             png_thread.join()
     t5 = time.perf_counter()
     if timings is not None:
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,
-                       total_s=t5 - t0, n_verts=len(verts), n_faces=len(faces))
-    return verts, faces, color
+                       total_s=t5 - t0, n_verts=n_verts, n_faces=n_faces, colour_rounds=len(rounds))
+        if exchange:
+            timings.update(pdist.stats_end())
+        if phases:
+            p5 = _prof_read(net, _l.PROF_GEMM)
+            timings.update(gemm_flop_reconstruction=p3[2] - p0[2], gemm_ms_reconstruction=p3[0] - p0[0],
+                           gemm_flop_normals=p5[2] - p3[2], gemm_ms_normals=p5[0] - p3[0])
+    return (verts, faces, color) if wants_result else None
 
 
 def _image_coloured_mesh(subj, res, net, cuda, data, save_path, thresh, use_octree):

@@ -20,19 +20,19 @@ def lib():
 def test_header_symbols_exported_and_bound(lib):
     header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
     declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header))
-    declared -= {'pifu_ctx', 'pifu_stream'}
+    declared -= {'pifu_ctx', 'pifu_stream', 'pifu_comm'}
     assert len(declared) >= 20
     handle = lib.load()
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in the header but not exported'
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert handle.pifu_abi_version() == lib.ABI_VERSION == 3
+    assert handle.pifu_abi_version() == lib.ABI_VERSION == 4
 
 
 def test_library_exports_exactly_the_header(lib):
     """No lab switches or diagnostics in the shipped library: its `pifu_*` exports are the header's declarations."""
     header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
-    declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header)) - {'pifu_ctx', 'pifu_stream'}
+    declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header)) - {'pifu_ctx', 'pifu_stream', 'pifu_comm'}
     lib.load()
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('pifu_')}

@@ -112,46 +112,83 @@ def test_normal_spans_follow_reference_colour_loop():
     assert _normal_spans(100000)[-1] == (100000, 100000)        # empty slice: the reference raises there (C-6)
 
 
-def _calls_worker(rank, ws, port, spans, q):
+def _rounds_worker(rank, ws, port, n_verts, interval, q):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=ws)
     import pifuhd_amd  # noqa: F401
-    from pifuhd_amd.dist import sharded_calls
-    seen = []
-
-    def call_fn(l, r):
-        seen.append((l, r))
-        rows = torch.arange(l, r, dtype=torch.float32)
-        return torch.stack([rows, rows * 2 + 1, -rows], 1)
-    out = sharded_calls(spans, call_fn, 3, torch.device('cpu'))
-    q.put((rank, seen, out.numpy() if rank == 0 else None))
+    from pifuhd_amd import dist as pdist
+    from pifuhd_amd.reconstruction import _normal_spans
+    spans = _normal_spans(n_verts, interval)
+    seen, prefix = [], []
+    out = torch.zeros(n_verts, 3)
+    pdist.stats_begin()
+    for (base, m) in pdist.colour_rounds(len(spans), ws, per_call_cap=3, target_rounds=2):
+        mine, (L, R), slot = pdist.round_rows(spans, base, m, ws, rank, interval)
+        local = torch.zeros(slot, 3)
+        if mine is not None:
+            seen.append(mine)
+            rows = torch.arange(mine[0], mine[1], dtype=torch.float32)
+            local[:mine[1] - mine[0]] = torch.stack([rows, rows * 2 + 1, -rows], 1)
+        full = pdist.all_gather_rows(torch.empty(ws * slot, 3), local)
+        out[L:R] = full[:R - L]
+        prefix.append((L, R))
+    st = pdist.stats_end()
+    q.put((rank, seen, prefix, out.numpy(), st))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize('ws', [2, 3])
-def test_sharded_calls_gloo(ws):
-    """Whole calc_normal calls are distributed; every call runs exactly once; one all-gather rebuilds all rows."""
-    spans = [(0, 7), (7, 14), (14, 21), (21, 28), (28, 30)]          # last call ragged, rows 30.. never visited
+def test_colour_rounds_gloo(ws):
+    """The colour loop of the sharded gen_mesh: whole calc_normal calls are dealt out in rounds, every call runs exactly
+    once, and after each round's all-gather the finished rows are a PREFIX of the vertex list in order (what the OBJ
+    writer's ready(upto) needs); the last vertex is never visited (SURVEY C-6)."""
+    interval, n_verts = 7, 7 * 11 + 3                       # 12 spans, the last one ragged and one row short
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_calls_worker, args=(r, ws, port, spans, q)) for r in range(ws)]
+    procs = [ctx.Process(target=_rounds_worker, args=(r, ws, port, n_verts, interval, q)) for r in range(ws)]
     for p in procs:
         p.start()
     res = [q.get(timeout=200) for _ in range(ws)]
     for p in procs:
         p.join(timeout=100)
         assert p.exitcode == 0
-    seen = sorted(s for (_, ss, _) in res for s in ss)
-    assert seen == spans
-    out = [o for (r, _, o) in res if r == 0][0]
-    rows = np.arange(30, dtype=np.float32)
-    assert np.array_equal(out, np.stack([rows, rows * 2 + 1, -rows], 1))
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.reconstruction import _normal_spans
+    spans = _normal_spans(n_verts, interval)
+    rows = np.arange(n_verts, dtype=np.float32)
+    want = np.stack([rows, rows * 2 + 1, -rows], 1)
+    want[-1] = 0
+    covered = []
+    for (_, seen, prefix, out, st) in res:
+        assert np.array_equal(out, want)
+        assert prefix[0][0] == 0 and prefix[-1][1] == n_verts - 1
+        assert all(a[1] == b[0] for a, b in zip(prefix, prefix[1:]))          # round k + 1 starts where round k ended
+        assert st['collectives'] == len(prefix) and st['collective_bytes'] > 0
+        for (l, r) in seen:                                                  # runs of whole spans
+            covered += [s for s in spans if l <= s[0] and s[1] <= r]
+    assert sorted(covered) == spans
+    per_rank = [sum(1 for s in spans if any(l <= s[0] and s[1] <= r for (l, r) in seen)) for (_, seen, _, _, _) in res]
+    assert max(per_rank) <= -(-len(spans) // ws)
+
+
+def test_colour_rounds_shapes():
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd.dist import colour_rounds
+    for n in (1, 2, 9, 10, 11, 86, 149, 400):
+        for ws in (1, 2, 3, 4, 8):
+            r = colour_rounds(n, ws)
+            assert r[0][0] == 0 and all(m >= 1 and m <= 10 for (_, m) in r)
+            assert all(b[0] == a[0] + ws * a[1] for a, b in zip(r, r[1:]))           # rounds tile the span list
+            assert r[-1][0] < n <= r[-1][0] + ws * r[-1][1]
+            assert sum(m for (_, m) in r) == -(-n // ws) or r[-1][0] + ws * r[-1][1] >= n
+    assert colour_rounds(86, 1) == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 10), (50, 9), (59, 9), (68, 9), (77, 9)]
+    assert [m for (_, m) in colour_rounds(86, 8)] == [3, 3, 3, 2]
 
 
 def test_slab_planes_cover_the_cell_layers_once():

@@ -44,11 +44,20 @@ def _worker(rank, ws, port, outdir):
     from pifuhd_amd import reconstruction
     netMR, data = _build()
     path = os.path.join(outdir, f'mesh_r{rank}.obj')
-    verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True)
+    verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, result_on='all')
+    # the default: only rank 0 copies the mesh to the host and returns it (and writes the same file again)
+    timings = {}
+    only0 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, timings=timings)
+    assert (only0 is None) == (rank != 0)
+    if rank == 0:
+        assert all(np.array_equal(a, b) for a, b in zip(only0, (verts, faces, color)))
+    # the exchange explains itself: collectives, their bytes and the time inside them (bench.py's N > 1 line)
+    assert timings['collectives'] >= 2 and timings['collective_bytes'] > 0 and timings['collective_s'] >= 0.0
+    assert timings['colour_rounds'] >= 1 and timings['n_verts'] == len(verts)
     # the same call with marching cubes over one slab per rank (the form `reconstruction` switches to at R >= 1024)
     from pifuhd_amd import dist as pdist
     pdist.SLAB_MC_MIN_RESOLUTION = 64
-    verts2, faces2, color2 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True)
+    verts2, faces2, color2 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, result_on='all')
     np.savez(os.path.join(outdir, f'out_r{rank}.npz'), verts=verts, faces=faces, color=color, verts2=verts2, faces2=faces2,
              color2=color2)
     dist.barrier()
@@ -102,13 +111,25 @@ def _rccl_worker(port, outdir):
     assert pdist.collective_active()
     got_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
     got_oct, n_got = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
-    got = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl.obj'), sharded=True)
+    got = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl.obj'), sharded=True, result_on='all')
     pdist.SLAB_MC_MIN_RESOLUTION = 64                  # marching cubes through its slab form: four more all-gathers
-    got_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl_slab.obj'), sharded=True)
+    got_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'rccl_slab.obj'), sharded=True, result_on='all')
+    # the same collectives through the C ABI's own RCCL communicator (pifu_comm_* / pifu_allgather_*: what a binding without
+    # torch.distributed calls); torch.distributed only carries the communicator id
+    pdist.SLAB_MC_MIN_RESOLUTION = 1024
+    pdist.use_native_comm('cuda')
+    nat_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
+    nat = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native.obj'), sharded=True, result_on='all')
+    pdist.SLAB_MC_MIN_RESOLUTION = 64                  # float64 / int32 all-gathers go through pifu_allgather_bytes
+    nat_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native_slab.obj'), sharded=True, result_on='all')
+    pdist.release_native_comm()
+    native_ok = (torch.equal(want_field, nat_field) and all(np.array_equal(a, b) for a, b in zip(want, nat))
+                 and all(np.array_equal(a, b) for a, b in zip(want, nat_slab))
+                 and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'native.obj')).read())
     t = torch.tensor([3.0], device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
-    ok = (torch.equal(want_field, got_field) and torch.equal(want_oct, got_oct) and n_want == n_got
+    ok = (native_ok and torch.equal(want_field, got_field) and torch.equal(want_oct, got_oct) and n_want == n_got
           and all(np.array_equal(a, b) for a, b in zip(want, got)) and float(t.item()) == 3.0
           and all(np.array_equal(a, b) for a, b in zip(want, got_slab))
           and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'rccl.obj')).read())
@@ -249,6 +270,12 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     gm = line['gen_mesh']
     assert 'error' not in gm['one_subject_sharded'] and gm['one_subject_sharded']['n_verts'] > 0
     assert 'error' not in gm['independent_subjects'] and gm['independent_subjects']['subjects'] == 2
+    # the legs explain themselves (first contact with an 8-GPU node): world, collectives, their bytes and the time inside them,
+    # the colour rounds; the independent subjects are timed warm, and every rank's host threads are bounded
+    oss = gm['one_subject_sharded']
+    assert oss['world'] == 2 and oss['result_on'] == 'rank0' and oss['collectives'] >= 2 and oss['collective_bytes'] > 0
+    assert oss['collective_s'] >= 0 and oss['collective_s_max_over_ranks'] >= 0 and oss['colour_rounds'] >= 1
+    assert gm['independent_subjects']['warmed'] is True and gm['host_threads_per_rank'] >= 2
     assert 'error' not in gm['config5_1024'], gm['config5_1024']
     assert gm['config5_1024']['mesh_identical_on_all_ranks'] and gm['config5_1024']['n_verts'] > 0
 
@@ -307,7 +334,7 @@ def _worker_1024(rank, ws, port, outdir):
     netMR, data = _build_1024()
     timings = {}
     verts, faces, color = reconstruction.gen_mesh(1024, netMR, 'cuda', data, os.path.join(outdir, f'm1024_r{rank}.obj'),
-                                                  sharded=True, timings=timings)
+                                                  sharded=True, timings=timings, result_on='all')
     with open(os.path.join(outdir, f'sha1024_r{rank}.txt'), 'w') as f:
         f.write(_digest(verts, faces, color))
     if rank == 0:

@@ -206,6 +206,63 @@ def test_full_size_encoders_to_occupancy_end_to_end(golden_dir):
     assert np.median(cos_px) > 0.999 and (cos_px > 0.9).mean() > 0.97
 
 
+def test_full_size_pifuhd_checkpoint_configuration_end_to_end(golden_dir, observed):
+    """The configuration of the published PIFuHD checkpoint (`MLP.py:37-41`: `mlp_norm` none builds no norm
+    layers; `Filter.py:37-46`: GroupNorm(32, C) in both HGFilters), END TO END at full size against the reference's own run
+    (`tests/golden/make_golden_r5.py`): `filter_global(512^2)` + `filter_local(1024^2)` + `query` on 4 096 points +
+    `calc_normal`.  The un-normalised MLP amplifies fp32 summation-order noise, so besides the north star's 1e-4
+    the occupancy is held to a multiple of the CPU oracle's own distance from the same golden - and both are recorded."""
+    from helpers import seeded_points
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import config, nets, synth
+    gold = np.load(os.path.join(golden_dir, 'e2e_full_pifuhd.npz'))
+    seed, n, lim = int(gold['seed_points_lim'][0]), int(gold['seed_points_lim'][1]), float(gold['seed_points_lim'][2])
+    oc = config.coarse_opt(mlp_norm='no', norm='group'); of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=float(gold['mlp_std'][0]), perturb=False)
+    assert not any('.norms.' in k for k in sd if k.startswith(('mlp.', 'netG.mlp.')))
+    last = sorted(k for k in sd if k.startswith('mlp.filters.') and k.endswith('.bias'))[-1]
+    sd[last] = sd[last] + float(gold['fine_last_bias_key_shift'][0])
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = synth.synthetic_inputs(1024, 3, seed=0)
+    netMR.filter_global(data['img_512'])
+    netMR.filter_local(data['img'][:, None])
+    fc, ff = netG.im_feat_list[-1], netMR.im_feat_list[-1]
+    e_fc = _rel(fc[0, ::16, ::8, ::8].cpu().numpy(), gold['feat_coarse_sub'])
+    e_ff = _rel(ff[0, ::4, ::32, ::32].cpu().numpy(), gold['feat_fine_sub'])
+    assert e_fc < 5e-4 and e_ff < 5e-4, (e_fc, e_ff)
+    pts = seeded_points(seed, n, lim=lim)
+    calib = data['calib']
+    # the oracle on the GPU's feature maps: what fp32 CPU arithmetic leaves on this case
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc.cpu(), ff.cpu()
+    with torch.no_grad():
+        o_fine = ref.query(pts, calib)[0, 0].numpy()
+        o_low = ref.preds_coarse[0, 0].numpy()
+    want, want_low = gold['preds'], gold['preds_low']
+    assert 0.2 < (want > 0.5).mean() < 0.8 and want.max() - want[want > 0].min() > 0.5     # a field with contrast
+    eo, eo_low = float(np.abs(o_fine - want).max()), float(np.abs(o_low - want_low).max())
+    netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)
+    preds, low = netMR.get_preds().cpu().numpy().reshape(-1), netG.get_preds().cpu().numpy().reshape(-1)
+    eg, eg_low = float(np.abs(preds - want).max()), float(np.abs(low - want_low).max())
+    from pifuhd_amd import _lib
+    _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_ALWAYS)
+    try:
+        netMR.query(pts[:, None], calib_local=calib[:, None], calib_global=calib)
+        eg_px = float(np.abs(netMR.get_preds().cpu().numpy().reshape(-1) - want).max())
+    finally:
+        _lib.call('pifu_set_pixel_tables', netMR._ctx.h, _lib.PIX_AUTO)
+    observed('e2e_full_pifuhd', gpu_fine=eg, gpu_coarse=eg_low, gpu_fine_pixel_tables=eg_px, oracle_fine=eo, oracle_coarse=eo_low,
+             feat_coarse_rel=e_fc, feat_fine_rel=e_ff)
+    assert np.array_equal(preds == 0, want == 0)
+    # north star 1e-4; and never more than a few times what the fp32 CPU oracle leaves from the same feature maps
+    for e, o in ((eg, eo), (eg_low, eo_low), (eg_px, eo)):
+        assert e < 1e-4 and e <= max(2e-5, 4 * o), (eg, eg_low, eg_px, eo, eo_low)
+    m = int(gold['nmls'].shape[1])
+    netMR.calc_normal(pts[:, None, :, :m], calib[:, None], calib)
+    cos = (netMR.nmls.cpu().numpy()[0] * gold['nmls']).sum(0)
+    assert np.median(cos) > 0.999 and (cos > 0.9).mean() > 0.95
+
+
 def test_overlapped_encoder_schedule_is_bit_identical():
     """`reconstruction._Subject` issues the two filter calls so that independent work overlaps (netF beside netB inside the
     coarse call, the coarse hourglass - left running by PIFU_ENC_DEFER_JOIN - beside the fine level, the fine image's upload

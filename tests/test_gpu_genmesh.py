@@ -492,3 +492,100 @@ def test_gen_mesh_failure_leaves_no_png_thread_behind(tmp_path):
     th = threading.Thread(target=lambda: other.update(buf=mesh_util.pinned_flat('png', 16, torch.float32, 'cuda:0')))
     th.start(); th.join()
     assert all(other['buf'].data_ptr() != mesh_util._pinned[k].data_ptr() for k in keys)
+
+
+@pytest.mark.timeout(900)
+def test_config3_network_octree_512_gen_mesh_as_the_metric_runs_it(tmp_path, observed):
+    """BASELINE config 3 exactly as bench.py times it (the second half of the metric): `gen_mesh(512, ...)` with the
+    two-level network on the bench's subject - RGB-D input, full-size encoders, name-seeded weights, octree refinement from
+    64^3 (`reconstruction.py:25-72`, `mesh_util.py:124-187`).  Too large for the CPU oracle as a whole, so it is pinned piece
+    by piece: (1) two calls give the same arrays and the same OBJ bytes; (2) the fused device loop and the level-by-level ABI
+    calls select the same number of points on every level and leave the identical float64 SDF; (3) on every level at least
+    three whole 5 000-point GroupNorm chunks - the first, one from the middle, the ragged last - agree with the CPU oracle
+    within the north star's 1e-4; (4) marching cubes on a 128^3 crop of the SDF around the surface is the serial oracle's
+    (`oracle/mc_lewiner.c`), vertices and faces bit for bit; (5) the returned mesh is the marching cubes of that SDF."""
+    import ctypes as C
+    import filecmp
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, config, mesh_util, nets, reconstruction, synth
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    R, chunk = 512, 5000
+    oc = config.coarse_opt(in_image_channels=6)
+    of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    data = synth.synthetic_inputs(1024, 6, seed=0)
+    netMR.filter_global(data['img_512'].cuda())
+    netMR.filter_local(data['img'].cuda()[:, None])
+    synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3)
+    calib_t = data['calib']
+
+    # (1) the call itself, twice
+    t1, t2 = {}, {}
+    a = reconstruction.gen_mesh(R, netMR, 'cuda', data, str(tmp_path / 'a.obj'), timings=t1)
+    a = tuple(np.array(x) for x in a)                      # the arrays are views of pinned slabs: keep copies
+    b = reconstruction.gen_mesh(R, netMR, 'cuda', data, str(tmp_path / 'b.obj'), timings=t2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert filecmp.cmp(tmp_path / 'a.obj', tmp_path / 'b.obj', shallow=False)
+    verts, faces, color = a
+    assert len(verts) > 1_000_000 and len(faces) > 2_000_000 and np.all(color[-1] == 0)
+    assert faces.min() == 0 and faces.max() == len(verts) - 1
+    del b
+
+    # (2) + (3): the octree level by level through the public entry points, sampled chunks against the oracle
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse = netG.im_feat_list[-1].cpu()
+    ref.feat_fine = netMR.im_feat_list[-1].cpu()
+    calib, cinv = mesh_util.calib_pair(calib_t)
+    ctx = netMR._ctx
+    st = _stream_ptr(ctx.device)
+    res_a = (C.c_int32 * 3)(R, R, R)
+    sdf2 = torch.empty(R, R, R, device='cuda', dtype=torch.float64)
+    notproc = torch.empty(R, R, R, device='cuda', dtype=torch.uint8)
+    _lib.call('pifu_octree_begin', ctx.h, R, _ptr(sdf2), _ptr(notproc), st)
+    reso, levels, worst = R // 64, [], {}
+    while reso > 0:
+        cnt = C.c_int64(0)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st)
+        n = cnt.value
+        levels.append((reso, n))
+        idx = torch.empty(n, device='cuda', dtype=torch.int64)
+        vals = torch.empty(n, device='cuda', dtype=torch.float32)
+        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
+        _lib.call('pifu_eval_lattice', ctx.h, res_a, cinv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+                  _ptr(idx), 0, n, chunk, 0, _ptr(vals), st)
+        nchunks = -(-n // chunk)
+        assert nchunks >= 3
+        err = 0.0
+        for c in sorted({0, nchunks // 2, nchunks - 1}):
+            lo, hi = c * chunk, min((c + 1) * chunk, n)
+            pts = mesh_util.lattice_points(R, cinv, idx[lo:hi].cpu().numpy()).astype(np.float32)
+            with torch.no_grad():
+                want = ref.query(torch.from_numpy(pts)[None], calib_t)[0, 0].numpy()
+            err = max(err, float(np.abs(vals[lo:hi].cpu().numpy() - want).max()))
+        worst['reso_%d' % reso] = err
+        assert err < 1e-4, (reso, err)
+        _lib.call('pifu_octree_commit', ctx.h, R, reso, 0.05, _ptr(idx), _ptr(vals), n, _ptr(sdf2), _ptr(notproc), st)
+        if reso <= 1:
+            break
+        reso //= 2
+    assert [r for r, _ in levels] == [8, 4, 2, 1] and levels[0][1] == 64 ** 3       # 0, 8, .., 504 on each axis: all below the never-evaluated last plane
+    sdf, n_eval = mesh_util.eval_grid_device(netMR, calib_t, R, chunk, True)
+    assert n_eval == sum(n for _, n in levels)                      # the fused loop evaluated the same points ...
+    assert torch.equal(sdf, sdf2)                                   # ... and left the identical field
+    del sdf2, notproc
+    observed('config3_512_octree', points_evaluated=n_eval, share_of_grid=n_eval / R ** 3, n_verts=len(verts),
+             total_s_first_call=t1['total_s'], total_s=t2['total_s'], **{'max_err_vs_oracle_' + k: v for k, v in worst.items()})
+
+    # (5) the mesh gen_mesh returned is the marching cubes of this field
+    gv, gf = mesh_util.marching_cubes_device(ctx, sdf, 0.5)
+    assert len(gv) == len(verts) and np.array_equal(gf.cpu().numpy()[:, ::-1], faces)
+    # (4) a 128^3 crop around the centre of the inside region against the serial oracle
+    inside = (sdf > 0.5).nonzero()
+    ctr = [int(inside[:, k].float().mean().item()) for k in range(3)]
+    lo = [min(max(c - 64, 0), R - 128) for c in ctr]
+    crop = sdf[lo[0]:lo[0] + 128, lo[1]:lo[1] + 128, lo[2]:lo[2] + 128].contiguous()
+    cv, cf = mesh_util.marching_cubes_device(ctx, crop, 0.5)
+    ov, of_ = O.marching_cubes_lewiner(crop.cpu().numpy(), 0.5)
+    assert len(ov) > 10000
+    assert np.array_equal(cf.cpu().numpy(), of_) and np.array_equal(cv.cpu().numpy().view(np.uint32), ov.view(np.uint32))

@@ -29,16 +29,51 @@ def _build(mlp_norm='group', feat_seed=7):
     return netG, netMR, sd, oc, of
 
 
+def _oracle_errors(gold, tag, mlp_norm):
+    """What the CPU oracle (torch fp32, `oracle/pifu_oracle.py`) itself leaves against the reference's goldens for one MLP
+    norm mode: the conditioning of the case, measured.  The un-normalised modes ('batch' in eval arithmetic with the
+    synthetic weights, 'no') amplify fp32 summation-order noise far more than GroupNorm does, so the bound a GPU result is
+    held to is relative to this, not a fixed multiple of the north star's 1e-4."""
+    from oracle import pifu_oracle as O
+    sd, oc, of = golden_nets(mlp_norm=mlp_norm)
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    calib = calib_tensor()
+    with torch.no_grad():
+        fine = ref.query(seeded_points(3, 700), calib)[0, 0].numpy()
+        e = {'a_fine': np.abs(fine - gold[f'{tag}_a_fine']).max(),
+             'a_coarse': np.abs(ref.preds_coarse[0, 0].numpy() - gold[f'{tag}_a_coarse']).max(),
+             'a_phi': np.abs(ref.phi[0, ::16].numpy() - gold[f'{tag}_a_phi_sub']).max()}
+        pts = seeded_points(4, 1200, lim=1.0)
+        out = [ref.query(pts[:, :, s:s + 500], calib)[0, 0].numpy() for s in range(0, 1200, 500)]
+        e['b_fine'] = np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max()
+        c, _ = ref.query_coarse(seeded_points(5, 300), calib)
+        e['c_coarse'] = np.abs(c[0, 0].numpy() - gold[f'{tag}_c_coarse']).max()
+    return {k: float(v) for k, v in e.items()}
+
+
+def _bound(err_oracle, ceiling=TOL, floor=2e-5):
+    """What a GPU result may be away from the reference's golden: never more than the north star's 1e-4 - in EVERY norm mode
+    (round 4 allowed the un-normalised modes 3e-4; what was observed is <= 2.4e-5, `profiles/r05_parity_observed.json`) - and,
+    so that a regression cannot hide inside that band, no more than eight times what the fp32 CPU oracle itself leaves on
+    the same golden (2e-5 at least: the oracle's own error moves with the host's thread count)."""
+    return min(ceiling, max(floor, 8.0 * err_oracle))
+
+
 @pytest.mark.parametrize('tag,mlp_norm', [('group', 'group'), ('batch', 'batch'), ('none', 'no')])
-def test_query_matches_reference_golden(gold, tag, mlp_norm):
+def test_query_matches_reference_golden(gold, observed, tag, mlp_norm):
+    """Occupancy, coarse occupancy and phi against the goldens of the imported reference, three MLP norm modes
+    (`MLP.py:37-41,65-69`; 'no' is what the published pifuhd.pt uses).  Every occupancy is held to the north star's 1e-4 AND
+    to a multiple of the CPU oracle's own error on the same golden (`_bound`), and the OBSERVED errors of both are recorded,
+    so a drift inside a loose band cannot pass unnoticed."""
     netG, netMR, *_ = _build(mlp_norm)
     calib = calib_tensor()
-    scale = 1.0 if mlp_norm == 'group' else 3.0
+    eo = _oracle_errors(gold, tag, mlp_norm)
     netMR.query(seeded_points(3, 700), calib)
     fine = netMR.get_preds()[0, 0].cpu().numpy()
-    assert np.abs(fine - gold[f'{tag}_a_fine']).max() < TOL * scale
-    assert np.abs(netG.preds[0, 0].cpu().numpy() - gold[f'{tag}_a_coarse']).max() < TOL * scale
-    assert np.abs(netG.phi[0, ::16].cpu().numpy() - gold[f'{tag}_a_phi_sub']).max() < 2e-3 * scale
+    eg = {'a_fine': np.abs(fine - gold[f'{tag}_a_fine']).max(),
+          'a_coarse': np.abs(netG.preds[0, 0].cpu().numpy() - gold[f'{tag}_a_coarse']).max(),
+          'a_phi': np.abs(netG.phi[0, ::16].cpu().numpy() - gold[f'{tag}_a_phi_sub']).max()}
     assert np.array_equal(fine == 0, gold[f'{tag}_a_fine'] == 0)          # bounding-box mask
     # chunked evaluation: 500 / 500 / 200
     pts = seeded_points(4, 1200, lim=1.0)
@@ -46,10 +81,15 @@ def test_query_matches_reference_golden(gold, tag, mlp_norm):
     for s in range(0, 1200, 500):
         netMR.query(pts[:, :, s:s + 500], calib)
         out.append(netMR.get_preds()[0, 0].cpu().numpy())
-    assert np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max() < TOL * scale
+    eg['b_fine'] = np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max()
     # coarse-only net
     netG.query(seeded_points(5, 300), calib)
-    assert np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max() < TOL * scale
+    eg['c_coarse'] = np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max()
+    observed(f'query_golden[{tag}]', **{f'gpu_{k}': v for k, v in eg.items()}, **{f'oracle_{k}': v for k, v in eo.items()})
+    for k in eg:
+        # phi is an un-squashed activation (|phi| up to ~10 and more without a norm): absolute 5e-4 (observed <= 8.4e-5)
+        bound = _bound(eo[k], 5e-4, 2e-4) if k == 'a_phi' else _bound(eo[k])
+        assert eg[k] <= bound, (tag, k, eg[k], eo[k], bound)
 
 
 def test_chunked_c_abi_equals_per_chunk_calls(gold):
@@ -476,7 +516,7 @@ def _pixel_tables(net, mode):
 
 
 @pytest.mark.parametrize('tag,mlp_norm', [('group', 'group'), ('batch', 'batch'), ('none', 'no')])
-def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
+def test_pixel_tables_match_reference_golden(gold, observed, tag, mlp_norm):
     """The goldens of `test_query_matches_reference_golden` (the imported reference's query / phi / coarse-only outputs, points
     up to 1.15 outside the box: zero-padded taps and both in-box masks) with the pixel tables forced on at these small
     sizes, and the distance to the per-point GEMM path on the same points."""
@@ -484,6 +524,7 @@ def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
     netG, netMR, *_ = _build(mlp_norm)
     calib = calib_tensor()
     scale = 1.0 if mlp_norm == 'group' else 3.0
+    eo = _oracle_errors(gold, tag, mlp_norm)
     pts = seeded_points(3, 700)
     netMR.query(pts, calib)
     canon = netMR.get_preds()[0, 0].cpu().numpy().copy(), netG.preds[0, 0].cpu().numpy().copy(), netG.phi[0].cpu().numpy().copy()
@@ -491,9 +532,11 @@ def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
     try:
         netMR.query(pts, calib)
         fine, coarse, phi = netMR.get_preds()[0, 0].cpu().numpy(), netG.preds[0, 0].cpu().numpy(), netG.phi[0].cpu().numpy()
-        assert np.abs(fine - gold[f'{tag}_a_fine']).max() < TOL * scale
-        assert np.abs(coarse - gold[f'{tag}_a_coarse']).max() < TOL * scale
-        assert np.abs(phi[::16] - gold[f'{tag}_a_phi_sub']).max() < 2e-3 * scale
+        eg = {'a_fine': np.abs(fine - gold[f'{tag}_a_fine']).max(), 'a_coarse': np.abs(coarse - gold[f'{tag}_a_coarse']).max(),
+              'a_phi': np.abs(phi[::16] - gold[f'{tag}_a_phi_sub']).max()}
+        observed(f'pixel_tables_golden[{tag}]', **{f'gpu_{k}': v for k, v in eg.items()})
+        assert eg['a_fine'] <= _bound(eo['a_fine']) and eg['a_coarse'] <= _bound(eo['a_coarse'])
+        assert eg['a_phi'] <= _bound(eo['a_phi'], 5e-4, 2e-4)
         assert np.array_equal(fine == 0, gold[f'{tag}_a_fine'] == 0)
         assert np.array_equal(coarse == 0, gold[f'{tag}_a_coarse'] == 0)
         assert not np.array_equal(fine, canon[0])                 # the other path did run
@@ -504,9 +547,9 @@ def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
         for s in range(0, 1200, 500):
             netMR.query(pts[:, :, s:s + 500], calib)
             out.append(netMR.get_preds()[0, 0].cpu().numpy())
-        assert np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max() < TOL * scale
+        assert np.abs(np.concatenate(out) - gold[f'{tag}_b_fine']).max() <= _bound(eo['b_fine'])
         netG.query(seeded_points(5, 300), calib)                   # coarse-only net
-        assert np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max() < TOL * scale
+        assert np.abs(netG.get_preds()[0, 0].cpu().numpy() - gold[f'{tag}_c_coarse']).max() <= _bound(eo['c_coarse'])
     finally:
         _pixel_tables(netMR, _lib.PIX_AUTO)
 
@@ -514,7 +557,7 @@ def test_pixel_tables_match_reference_golden(gold, tag, mlp_norm):
 def test_pixel_tables_follow_the_feature_map_and_the_flags():
     """The table belongs to one feature map: a new map (also one whose pixel count is not a multiple of the 128-row GEMM
     tile: 20 x 20) is picked up by the next call; PIFU_Q_NO_COLUMN_SHARING on a call keeps the per-point GEMMs whatever the
-    mode; mode 1 switches at PIFU_PIXEL_TABLE_MIN_POINTS points."""
+    mode; mode 1 switches at max(PIFU_PIXEL_TABLE_MIN_POINTS, H * W) points."""
     import ctypes as C
     from pifuhd_amd import _lib
     from pifuhd_amd.nets import _ptr, _stream_ptr
@@ -555,6 +598,20 @@ def test_pixel_tables_follow_the_feature_map_and_the_flags():
         _pixel_tables(netMR, _lib.PIX_OFF)
         off = run(big, 0)
         assert not np.array_equal(auto, off) and np.abs(auto - off).max() < 2e-5
+        # a LARGER map moves the automatic threshold to its pixel count (building the table of an H x W map costs what H * W
+        # points cost through the per-point GEMMs): 160 x 160 = 25 600 pixels - a 20 000-point call keeps the per-point
+        # GEMMs (bit-identical to mode 0), a 26 000-point call takes the tables
+        fc, ff = seeded_features(10, hc=160)
+        netG.set_features(fc)
+        netMR.set_features(ff)
+        pts_l = seeded_points(23, 26000, lim=1.0).cuda().contiguous()
+        off_s, off_l = run(pts_l[:, :, :20000].contiguous(), 0), run(pts_l, 0)
+        _pixel_tables(netMR, _lib.PIX_AUTO)
+        assert _lib.load().pifu_arena_bytes(netMR._ctx.h, _lib.ARENA_PIXEL) < 160 * 160 * 1536 * 4       # not rebuilt for this map yet
+        assert np.array_equal(run(pts_l[:, :, :20000].contiguous(), 0), off_s)
+        auto_l = run(pts_l, 0)
+        assert not np.array_equal(auto_l, off_l) and np.abs(auto_l - off_l).max() < 2e-5
+        assert _lib.load().pifu_arena_bytes(netMR._ctx.h, _lib.ARENA_PIXEL) >= 160 * 160 * 1536 * 4
     finally:
         _pixel_tables(netMR, _lib.PIX_AUTO)
 
@@ -610,7 +667,9 @@ def test_workspace_limit_runs_smaller_batches_with_identical_results():
     try:
         _lib.call('pifu_set_workspace_limit', h, 160 << 20)             # 160 MB: ~12 000 rows per batch instead of 262 144
         got = run_all()
-        assert _lib.load().pifu_workspace_bytes(h) < big and _lib.load().pifu_workspace_bytes(h) < (160 << 20) + (300 << 20)
+        assert _lib.load().pifu_workspace_bytes(h) < big
+        # the bound is a bound: the query arena itself (no allocation slack), the other arenas are not covered by it
+        assert 0 < _lib.load().pifu_arena_bytes(h, _lib.ARENA_QUERY) <= (160 << 20)
         for a, b in zip(want, got):
             assert torch.equal(a, b)
         _lib.call('pifu_set_workspace_limit', h, 1 << 20)               # below one 5 000-point chunk's 66 MB

@@ -1,6 +1,6 @@
 """Point the ctypes binding at the lab build (tools/lab/libpifuhd_lab.so) instead of the product library.
 
-    import lab; lab.use()        # before the first pifuhd_amd call; builds the library if it is missing
+    import lab; lab.use()        # before the first pifuhd_amd call; (re)builds the library when it is missing or older than its sources
 
 The lab library is the product sources compiled with -DPIFU_LAB: same ABI plus the PIFU_* environment switches, the
 predecessor GEMM kernels and pifu_debug_read.  Nothing under rgb-d-pifuhd_amd/ knows about it.
@@ -22,8 +22,7 @@ def build(experiments=False):
 def use(experiments=False):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    if not os.path.exists(LAB_PATH):
-        build(experiments)
+    build(experiments)          # make: a no-op when the library is newer than the product sources it is compiled from
     import pifuhd_amd  # noqa: F401
     from pifuhd_amd import _lib
     prev = (_lib.LIB_PATH, _lib._lib)
