@@ -141,10 +141,10 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
-    # N processes share this host: each one's OBJ writer / PNG encoder gets its share of the cores, not all of them
+    # N processes share this host: where EVERY rank writes a file (the independent subjects) each one's OBJ writer / PNG encoder
+    # gets its share of the cores, not all of them; where only rank 0 writes (the sharded legs) it may use the machine
     host_threads = max(2, (os.cpu_count() or 8) // max(world, 1))
-    recon.set_host_threads(host_threads)
-    res['host_threads_per_rank'] = host_threads
+    res['host_threads_per_rank_independent_subjects'] = host_threads
     extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds')
 
     with tempfile.TemporaryDirectory() as td:
@@ -176,6 +176,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         # own image first: the first call with a new mesh size allocates (pinned result slabs, arenas), which is not the
         # steady state of a recon() loop over many subjects
         err, t_tot = None, float('inf')
+        recon.set_host_threads(host_threads)
         try:
             own = synth.synthetic_inputs(1024, args.image_channels, seed=rank)
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subjwarm{rank}.obj'))
@@ -187,6 +188,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             t_tot = time.perf_counter() - t0
         except Exception as e:
             err = repr(e)
+        recon.set_host_threads(0)
         red = reduce_max([t_tot])
         if red[0] != float('inf'):
             res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3),
@@ -253,6 +255,7 @@ def main():
                     help='functional check, never a measurement: initialise the process group (backend nccl = RCCL) even with ONE '
                          'rank and run every collective of the sharded path (all-gather of the field, of the colours, barrier)')
     ap.add_argument('--no-chunk100k', action='store_true', help='skip the extra pass in 100 000-point chunks')
+    ap.add_argument('--no-encoder-leg', action='store_true', help='skip the timed encoder passes (roofline_secondary: encoders)')
     ap.add_argument('--no-canonical', action='store_true', help='skip the extra canonical per-point pass (no column sharing)')
     ap.add_argument('--canonical-steps', type=int, default=2)
     ap.add_argument('--no-cpu-genmesh', action='store_true', help='skip the CPU (oracle) gen_mesh baseline at --cpu-genmesh-res')
@@ -651,7 +654,7 @@ def main():
 
     # ---- the encoder pass (filter_global + filter_local of one image, the overlapped schedule gen_mesh uses): counted
     # convolution FLOPs / wall time of a steady-state pass against the fp32-matrix peak
-    if world == 1 and args.features == 'filter':
+    if world == 1 and args.features == 'filter' and not args.no_encoder_leg:
         try:
             from pifuhd_amd import reconstruction as recon_enc
             recon_enc._Subject(netMR, data)

@@ -81,7 +81,7 @@ enum {
  *      pifu_set_pixel_tables, pifu_set_workspace_limit added.
  *   4: round 5 - the automatic pixel-table threshold follows the coarse map (calls of at least max(16 384, H * W) points: the
  *      same as before for the 128^2 map, later for larger maps); pifu_set_workspace_limit is a hard bound of the query arena (no allocation slack);
- *      pifu_arena_bytes, pifu_set_host_threads and the pifu_comm_* / pifu_allgather_* calls added;
+ *      pifu_arena_bytes, pifu_set_host_threads, pifu_enc_set_param_device and the pifu_comm_* / pifu_allgather_* calls added;
  *      a context may be used from several streams: the pixel table is ordered against its builder and its readers by events. */
 #define PIFU_ABI_VERSION 4
 const char *pifu_last_error(void);
@@ -160,6 +160,13 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
  * pifu_filter_fine = PIFuMRNet.filter_local (PIFuMRNet.py:83-118, rect = None): normals (NCHW, Hn x Wn) are
  * resized bilinearly (align_corners) to H x W, concatenated, HGFilter('no_down'); output [1][hg_dim][H/2][W/2]. */
 int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
+/* The same registration for a rank-4 convolution weight that already lives on the device (a checkpoint loaded to the GPU):
+ * the library takes its own device copy (stream-ordered on `stream`, which is synchronised) - no host round trip.  Either way
+ * the [Cout][Cin][k][k] tensors are repacked into the kernels' K-run layout BY A KERNEL on first use (1.5 GB of weights:
+ * milliseconds instead of the 1.7 s a host loop + pageable upload took); vectors (biases, norm parameters, running
+ * statistics) go through pifu_enc_set_param, their folding happens on the host. */
+int pifu_enc_set_param_device(pifu_ctx *ctx, const char *name, const float *dev_data, const int64_t *shape, int rank,
+                              pifu_stream stream);
 int pifu_enc_clear(pifu_ctx *ctx);
 int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                        int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,

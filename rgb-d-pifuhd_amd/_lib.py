@@ -60,6 +60,7 @@ SIGNATURES = {
     'pifu_set_depth_normalizer': (_i32, [_p, _f, _f]),
     'pifu_set_features': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
     'pifu_enc_set_param': (_i32, [_p, C.c_char_p, _p, _p, _i32]),
+    'pifu_enc_set_param_device': (_i32, [_p, C.c_char_p, _p, _p, _i32, _p]),
     'pifu_enc_clear': (_i32, [_p]),
     'pifu_filter_coarse': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'pifu_filter_fine': (_i32, [_p, _p, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -661,6 +661,35 @@ __global__ void k_nhwc_to_nchw(const float *src, int ld, int C, int HW, float *d
     }
 }
 
+// ---- weight packing on the device ---------------------------------------------------------------------------------
+// dst [cout_pad][ldw] <- a Conv2d weight [cout][d1][kh][kw] (or ConvTranspose2d [ci][cout][kh][kw]): per K run (span) the
+// taps (ky, kx[i]) of `nx` consecutive pixels, C channels each (zero beyond the weight's `ci` and where a run is padded to
+// the K step).  One thread per destination element: the 1.5 GB of encoder weights are repacked at HBM speed on first use
+// instead of in a scalar host loop followed by a pageable upload (1.7 s of the first pass).
+struct PackArgs {
+    const float *src; float *dst;
+    int cout, cout_pad, ci, C, d1, kh, kw, transposed, nspan, ldw;
+    int base[CONV_MAX_SPANS + 1], nx[CONV_MAX_SPANS], ky[CONV_MAX_SPANS], kx[CONV_MAX_SPANS][7];
+};
+
+__global__ void k_pack_weight(const PackArgs a)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)a.cout_pad * a.ldw) return;
+    const int o = (int)(idx / a.ldw), col = (int)(idx % a.ldw);
+    int s = 0;
+    while (s + 1 < a.nspan && col >= a.base[s + 1]) ++s;
+    const int r = col - a.base[s], i = r / a.C, c = r % a.C;
+    float v = 0.f;
+    if (o < a.cout && i < a.nx[s] && c < a.ci) {
+        const int ky = a.ky[s], kx = a.kx[s][i];
+        const size_t src = a.transposed ? ((((size_t)c * a.d1 + o) * a.kh + ky) * a.kw + kx)
+                                        : ((((size_t)o * a.d1 + c) * a.kh + ky) * a.kw + kx);
+        v = a.src[src];
+    }
+    a.dst[idx] = v;
+}
+
 // ======================================================================================================
 // host side: tensors, parameter registry, graph execution
 // ======================================================================================================
@@ -680,8 +709,10 @@ struct Affine {           // per-channel transform applied by the consumer
 };
 
 struct HostParam {
-    std::vector<float> data;
+    std::vector<float> data;                     // host values (pifu_enc_set_param); empty for pifu_enc_set_param_device
     std::vector<int64_t> shape;
+    float *raw = nullptr;                        // the tensor as given, on the device (owned): what the packing kernels read
+    size_t count() const { size_t n = 1; for (int64_t d : shape) n *= (size_t)d; return n; }
 };
 
 // A lane = one in-order chain of launches with the buffers only it touches.  Nets that do not depend on each other run in
@@ -700,9 +731,16 @@ struct Lane {
 struct EncState {
     std::map<std::string, HostParam> params;
     std::map<std::string, float *> dev;          // packed device arrays (weights, biases, taps, fixed affines)
-    Lane lanes[3];
+    Lane lanes[5];                               // 0 caller / netF / fine level, 1 netB, 2 coarse hourglass, 3 - 4 hourglass branches
     Lane *cur = &lanes[0];                       // the lane the host routine is currently issuing into
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_coarse = nullptr;
+    // An hourglass level is two independent chains until its final add (Filter.py:104-127): up1 = b1(x) at the level's own
+    // resolution, and pool -> b2 -> (next level) -> b3 at half of it.  While `branch_free` lanes are left, a level issues its
+    // low chain into a branch lane and its up1 block into the lane it was called on: the low chain's many small launches
+    // (statistics, prepared inputs, 32-wide tiles on quarter-size maps) run beside the big convolutions of up1 instead of
+    // between them.  Same kernels, same arithmetic: bit-identical results.
+    int branch_free = 0, branch_next = 3;
+    hipEvent_t ev_bfork[2] = {nullptr, nullptr}, ev_bjoin[2] = {nullptr, nullptr};
     bool coarse_pending = false;                 // the deferred coarse hourglass has been issued and not yet joined
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
@@ -760,7 +798,7 @@ Tensor slice(const Tensor &t, int c0, int c)
     return s;
 }
 
-const HostParam &param(EncState &S, const std::string &name)
+HostParam &param(EncState &S, const std::string &name)
 {
     auto it = S.params.find(name);
     if (it == S.params.end()) throw Fail{"missing encoder parameter " + name};
@@ -874,30 +912,49 @@ struct KSpan {
     int kx[7] = {0};
 };
 
-// weights -> [cout_pad][sum over spans of roundup(nx * C, 32)], zero where a run is padded to the K step
-const float *packed_dma_weight(EncState &S, const std::string &key, const HostParam &w, bool transposed, int C, int cout,
-                               int cout_pad, const std::vector<KSpan> &spans, int *ldw_out)
+// the parameter as given, on the device: uploaded once from the host copy (pifu_enc_set_param) or already there
+// (pifu_enc_set_param_device)
+const float *raw_on_device(EncState &S, const std::string &name, HostParam &w)
+{
+    if (w.raw) return w.raw;
+    if (w.data.empty()) throw Fail{name + ": parameter has neither host nor device values"};
+    if (hipMalloc(&w.raw, w.data.size() * sizeof(float)) != hipSuccess) throw Fail{"hipMalloc failed for " + name};
+    if (hipMemcpyAsync(w.raw, w.data.data(), w.data.size() * sizeof(float), hipMemcpyHostToDevice, S.cur->st) != hipSuccess)
+        throw Fail{"upload failed for " + name};
+    return w.raw;
+}
+
+// weights -> [cout_pad][sum over spans of roundup(nx * C, 32)], zero where a run is padded to the K step (k_pack_weight)
+const float *packed_dma_weight(EncState &S, const std::string &key, const std::string &wname, HostParam &w, bool transposed, int C,
+                               int cout, int cout_pad, const std::vector<KSpan> &spans, int *ldw_out)
 {
     int ldw = 0;
     for (const KSpan &s : spans) ldw += (int)round_up((int64_t)s.nx * C, BK);
     *ldw_out = ldw;
     if (S.dev.count(key)) return S.dev[key];
-    const int d0 = (int)w.shape[0], d1 = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
-    const int ci = transposed ? d0 : d1;
-    if (ci > C) throw Fail{key + ": input channels exceed the prepared width"};
-    std::vector<float> pk((size_t)cout_pad * ldw, 0.f);
+    if ((int)spans.size() > CONV_MAX_SPANS) throw Fail{key + ": too many K runs"};
+    PackArgs a{};
+    a.src = raw_on_device(S, wname, w);
+    a.cout = cout; a.cout_pad = cout_pad; a.C = C; a.ldw = ldw; a.transposed = transposed ? 1 : 0;
+    a.d1 = (int)w.shape[1]; a.kh = (int)w.shape[2]; a.kw = (int)w.shape[3];
+    a.ci = transposed ? (int)w.shape[0] : (int)w.shape[1];
+    if (a.ci > C) throw Fail{key + ": input channels exceed the prepared width"};
+    a.nspan = (int)spans.size();
     int base = 0;
-    for (const KSpan &s : spans) {
-        for (int o = 0; o < cout; ++o)
-            for (int i = 0; i < s.nx; ++i)
-                for (int c = 0; c < ci; ++c) {
-                    const size_t src = transposed ? ((((size_t)c * d1 + o) * kh + s.ky) * kw + s.kx[i])
-                                                  : ((((size_t)o * d1 + c) * kh + s.ky) * kw + s.kx[i]);
-                    pk[(size_t)o * ldw + base + i * C + c] = w.data[src];
-                }
-        base += (int)round_up((int64_t)s.nx * C, BK);
+    for (int k = 0; k < a.nspan; ++k) {
+        a.base[k] = base; a.nx[k] = spans[k].nx; a.ky[k] = spans[k].ky;
+        for (int i = 0; i < 7; ++i) a.kx[k][i] = spans[k].kx[i];
+        base += (int)round_up((int64_t)spans[k].nx * C, BK);
     }
-    return dev_upload(S, key, pk);
+    a.base[a.nspan] = base;
+    float *d = nullptr;
+    const size_t n = (size_t)cout_pad * ldw;
+    if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) throw Fail{"hipMalloc failed for " + key};
+    a.dst = d;
+    // on the lane's stream: ordered before the convolution that reads it; a packed copy is written once and only read after
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S.cur->st, a);
+    S.dev[key] = d;
+    return d;
 }
 
 // N tile of a DMA convolution: no wider than the output needs and never 128 - the 128 x 64 tile keeps three blocks per CU
@@ -988,7 +1045,7 @@ void conv2d(EncState &S, const std::string &wname, const std::string &bname, con
             const ConvGeom &g, Tensor &out, const Tensor *residual = nullptr)
 {
     if (x.ld % 4 || x.C % BK) throw Fail{wname + ": input channels must be padded to 32"};
-    const HostParam &wp = param(S, wname);
+    HostParam &wp = param(S, wname);
     if (wp.shape.size() != 4) throw Fail{wname + ": expected a 4-d conv weight"};
     const int co = (int)wp.shape[0], ci = (int)wp.shape[1], kk = (int)wp.shape[2];
     if (co != out.C || kk != g.k) throw Fail{wname + ": shape mismatch"};
@@ -1007,7 +1064,7 @@ void conv2d(EncState &S, const std::string &wname, const std::string &bname, con
             for (int i = 0; i < g.k; ++i) spans[ky].kx[i] = i;
         }
         ConvDmaArgs a{};
-        a.W = packed_dma_weight(S, wname + "#dma" + std::to_string(Cp) + "_" + std::to_string(tn), wp, false, Cp, co, cout_pad, spans, &a.ldw);
+        a.W = packed_dma_weight(S, wname + "#dma" + std::to_string(Cp) + "_" + std::to_string(tn), wname, wp, false, Cp, co, cout_pad, spans, &a.ldw);
         a.bias = packed_bias(S, bname.empty() ? wname + "#nobias" : bname, cout_pad, !bname.empty());
         a.P = prepare_input(S, x, act, Cp, g.pad, Hp, Wp, g.reflect, &a.p_bytes);
         a.Wp = Wp; a.C = Cp; a.RW = out.W; a.nrows = nrows; a.is = g.stride;
@@ -1028,7 +1085,7 @@ void conv2d(EncState &S, const std::string &wname, const std::string &bname, con
 void conv_transpose2d(EncState &S, const std::string &wname, const std::string &bname, const Tensor &x, const Affine &act,
                       Tensor &out)
 {
-    const HostParam &w = param(S, wname);            // [Cin][Cout][3][3]
+    HostParam &w = param(S, wname);                  // [Cin][Cout][3][3]
     const int ci = (int)w.shape[0], co = (int)w.shape[1];
     if (ci != x.C || co != out.C || out.H != 2 * x.H || out.W != 2 * x.W) throw Fail{wname + ": transposed conv shape mismatch"};
     {
@@ -1052,8 +1109,8 @@ void conv_transpose2d(EncState &S, const std::string &wname, const std::string &
                     spans.push_back(sp);
                 }
                 ConvDmaArgs a{};
-                a.W = packed_dma_weight(S, wname + "#dmaT" + std::to_string(py) + std::to_string(px) + "_" + std::to_string(tn), w, true, Cp, co,
-                                        cout_pad, spans, &a.ldw);
+                a.W = packed_dma_weight(S, wname + "#dmaT" + std::to_string(py) + std::to_string(px) + "_" + std::to_string(tn), wname, w, true,
+                                        Cp, co, cout_pad, spans, &a.ldw);
                 a.bias = bias;
                 a.P = P; a.p_bytes = p_bytes; a.Wp = Wp; a.C = Cp; a.RW = x.W; a.nrows = x.H * x.W; a.is = 1;
                 a.nspan = (int)spans.size();
@@ -1120,11 +1177,33 @@ Tensor avg_pool(EncState &S, const Tensor &x)
 
 Tensor hourglass(EncState &S, const std::string &p, int level, const Tensor &x)
 {
-    Tensor up1 = conv_block(S, p + ".b1_" + std::to_string(level), x, x.C);
-    Tensor low = conv_block(S, p + ".b2_" + std::to_string(level), avg_pool(S, x), x.C);
-    if (level > 1) low = hourglass(S, p, level - 1, low);
-    else low = conv_block(S, p + ".b2_plus_" + std::to_string(level), low, x.C);
-    low = conv_block(S, p + ".b3_" + std::to_string(level), low, x.C);
+    Tensor up1, low;
+    const auto low_chain = [&]() {
+        Tensor l = conv_block(S, p + ".b2_" + std::to_string(level), avg_pool(S, x), x.C);
+        if (level > 1) l = hourglass(S, p, level - 1, l);
+        else l = conv_block(S, p + ".b2_plus_" + std::to_string(level), l, x.C);
+        return conv_block(S, p + ".b3_" + std::to_string(level), l, x.C);
+    };
+    if (S.branch_free > 0) {
+        // the low chain on a branch lane (it continues from what this lane has issued: x is complete there), up1 here
+        Lane *here = S.cur;
+        const int b = S.branch_next++;
+        --S.branch_free;
+        Lane *br = &S.lanes[b];
+        if (hipEventRecord(S.ev_bfork[b - 3], here->st) != hipSuccess || hipStreamWaitEvent(br->st, S.ev_bfork[b - 3], 0) != hipSuccess)
+            throw Fail{"hourglass: fork of the branch lane failed"};
+        S.cur = br;
+        low = low_chain();
+        S.cur = here;
+        up1 = conv_block(S, p + ".b1_" + std::to_string(level), x, x.C);
+        if (hipEventRecord(S.ev_bjoin[b - 3], br->st) != hipSuccess || hipStreamWaitEvent(here->st, S.ev_bjoin[b - 3], 0) != hipSuccess)
+            throw Fail{"hourglass: join of the branch lane failed"};
+        --S.branch_next;                        // the lane is free again for the next stack's hourglass
+        ++S.branch_free;
+    } else {
+        up1 = conv_block(S, p + ".b1_" + std::to_string(level), x, x.C);
+        low = low_chain();
+    }
     Tensor out = new_tensor(S, x.H, x.W, x.C);
     hipLaunchKernelGGL(k_bicubic_up2_add, dim3(nblk(out.pixels() * (x.C / 4), 256)), dim3(256), 0, S.cur->st, (const float *)low.p, low.ld,
                        low.H, low.W, (const float *)up1.p, up1.ld, out.p, out.ld, x.C);
@@ -1215,15 +1294,19 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     }
     // ReflectionPad(3) + Conv7x7 (64 -> 3) + Tanh
     const std::string m = p + ".model." + std::to_string(idx + 1);
-    const HostParam &w = param(S, m + ".weight");
+    HostParam &w = param(S, m + ".weight");
     const std::string key = m + "#w7";
     if (!S.dev.count(key)) {
+        // [3][ci][7][7] -> [3][49][ci]: seven K runs (one per kernel row) of seven taps, ci channels each
         const int ci = (int)w.shape[1];
-        std::vector<float> pk((size_t)3 * 49 * ci);
-        for (int o = 0; o < 3; ++o)
-            for (int cc = 0; cc < ci; ++cc)
-                for (int t = 0; t < 49; ++t) pk[((size_t)o * 49 + t) * ci + cc] = w.data[((size_t)o * ci + cc) * 49 + t];
-        dev_upload(S, key, pk);
+        if ((7 * ci) % BK) throw Fail{"k_conv7_to3_tanh: 7 * Cin must be a multiple of 32"};
+        std::vector<KSpan> spans(7);
+        for (int ky = 0; ky < 7; ++ky) {
+            spans[ky].nx = 7; spans[ky].ky = ky;
+            for (int i = 0; i < 7; ++i) spans[ky].kx[i] = i;
+        }
+        int ldw = 0;
+        packed_dma_weight(S, key, m + ".weight", w, false, ci, 3, 3, spans, &ldw);
     }
     const float *bias = dev_upload(S, m + ".bias", param(S, m + ".bias").data);
     if (x.C % 16 != 0) throw Fail{"k_conv7_to3_tanh needs a multiple of 16 input channels"};
@@ -1247,7 +1330,14 @@ int begin(pifu_ctx *ctx, EncState &S, int k, size_t arena_bytes, hipStream_t st)
     PIFU_HIP(hipSetDevice(ctx->device));
     Lane &L = S.lanes[k];
     if (k == 0) L.st = st;
-    else {
+    else if (k == 3) {
+        // the first hourglass branch lane issues into netB's stream, which is idle by the time a hourglass runs on lane 0: the
+        // runtime deals streams out over a few hardware queues (four by default) in order of creation, and a stream that
+        // lands on the queue of the lane it is meant to run beside would be serialised with it
+        Lane &B = S.lanes[1];
+        if (!B.own) PIFU_HIP(hipStreamCreateWithFlags(&B.own, hipStreamNonBlocking));
+        L.st = B.own;
+    } else {
         if (!L.own) PIFU_HIP(hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking));
         L.st = L.own;
     }
@@ -1299,14 +1389,44 @@ int pifu_enc_join(pifu_ctx *ctx, hipStream_t st)
     return PIFU_OK;
 }
 
+static int set_param(pifu_ctx *ctx, const char *name, const float *host, const float *dev, const int64_t *shape, int rank,
+                     hipStream_t st);
+
 extern "C" int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host, const int64_t *shape, int rank)
 {
     PIFU_REQUIRE(ctx && name && host && shape && rank >= 0 && rank <= 4, PIFU_ERR_INVALID, "pifu_enc_set_param: bad argument");
+    return set_param(ctx, name, host, nullptr, shape, rank, nullptr);
+}
+
+extern "C" int pifu_enc_set_param_device(pifu_ctx *ctx, const char *name, const float *dev, const int64_t *shape, int rank,
+                                         pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && name && dev && shape && rank == 4, PIFU_ERR_INVALID,
+                 "pifu_enc_set_param_device: bad argument (rank-4 convolution weights only)");
+    return set_param(ctx, name, nullptr, dev, shape, rank, (hipStream_t)stream);
+}
+
+static int set_param(pifu_ctx *ctx, const char *name, const float *host, const float *dev, const int64_t *shape, int rank,
+                     hipStream_t st)
+{
     EncState &S = state_of(ctx);
     HostParam hp;
     size_t n = 1;
     for (int i = 0; i < rank; ++i) { hp.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
-    hp.data.assign(host, host + n);
+    PIFU_HIP(hipSetDevice(ctx->device));
+    auto old = S.params.find(name);
+    if (old != S.params.end() && old->second.raw) {      // a filter pass may still be packing from the previous copy
+        PIFU_HIP(hipDeviceSynchronize());
+        (void)hipFree(old->second.raw);
+        old->second.raw = nullptr;
+    }
+    if (host) hp.data.assign(host, host + n);
+    else {
+        // the library's own copy: the caller may free or overwrite its tensor as soon as its stream has passed this point
+        PIFU_HIP(hipMalloc(&hp.raw, n * sizeof(float)));
+        PIFU_HIP(hipMemcpyAsync(hp.raw, dev, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        PIFU_HIP(hipStreamSynchronize(st));            // the packing kernels run on the lanes' streams, later
+    }
     S.params[name] = std::move(hp);
     // drop every packed copy derived from this parameter: keys `<name>...` (packed weights / biases) and keys
     // `<module>#...` derived from several tensors of the owning module (folded eval-mode BatchNorm `<module>#bn_eval.s/.b`
@@ -1334,13 +1454,16 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &kv : it->second->dev) (void)hipFree(kv.second);
+    for (auto &kv : it->second->params)
+        if (kv.second.raw) (void)hipFree(kv.second.raw);
     for (Lane &L : it->second->lanes) {
         if (L.arena.p) (void)hipFree(L.arena.p);
         if (L.splitk.p) (void)hipFree(L.splitk.p);
         if (L.prep.p) (void)hipFree(L.prep.p);
         if (L.own) (void)hipStreamDestroy(L.own);
     }
-    for (hipEvent_t e : {it->second->ev_fork, it->second->ev_join, it->second->ev_coarse})
+    for (hipEvent_t e : {it->second->ev_fork, it->second->ev_join, it->second->ev_coarse, it->second->ev_bfork[0], it->second->ev_bfork[1],
+                         it->second->ev_bjoin[0], it->second->ev_bjoin[1]})
         if (e) (void)hipEventDestroy(e);
     delete it->second;
     g_states.erase(it);
@@ -1447,11 +1570,26 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
     int rc = begin(ctx, S, 0, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
     if (rc) return rc;
+    // the two upper hourglass levels issue their low chains into branch lanes (EncState::branch_free)
+    for (int b = 0; b < 2; ++b) {
+        if (!S.ev_bfork[b]) {
+            PIFU_HIP(hipEventCreateWithFlags(&S.ev_bfork[b], hipEventDisableTiming));
+            PIFU_HIP(hipEventCreateWithFlags(&S.ev_bjoin[b], hipEventDisableTiming));
+        }
+        // a low chain holds ~6 tensors of 256 channels at a quarter of its level's pixels (1.5 KB per pixel of the level) plus
+        // what the levels below it add (a third of that again) and the statistics partials: 3 KB per pixel, per stack
+        rc = begin(ctx, S, 3 + b, (px >> (2 * b)) * 4 * (size_t)750 * num_stack + ((size_t)64 << 20), (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    S.cur = &S.lanes[0];
+    S.branch_free = hg_depth >= 2 ? 2 : hg_depth;
+    S.branch_next = 3;
     try {
         Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
         S.norm = norm;
         S.fuse_stats = norm != 0;
         Tensor f = hg_filter(S, "fine.image_filter", in, num_stack, hg_depth, hg_dim, false);
+        S.branch_free = 0;
         FeatMap &fm = ctx->feat[1];
         const size_t bytes = f.pixels() * f.C * sizeof(float);
         if (bytes > fm.bytes) {
@@ -1467,6 +1605,8 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
             hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(nblk(f.pixels(), 32), nblk(f.C, 32)), dim3(256), 0, S.cur->st, (const float *)f.p, f.ld, f.C,
                                (int)f.pixels(), feat_nchw);
     } catch (const Fail &e) {
+        S.cur = &S.lanes[0];
+        S.branch_free = 0;
         pifu_set_error("pifu_filter_fine: %s", e.msg.c_str());
         return PIFU_ERR_STATE;
     }

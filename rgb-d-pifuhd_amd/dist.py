@@ -195,24 +195,23 @@ def shard_range(n_items: int, world_size: int, rank: int):
     return i0, min(i0 + per, n_items), per
 
 
-def colour_rounds(n_spans, ws, per_call_cap=10, target_rounds=4):
+def colour_rounds(n_spans, ws, per_call_cap=10):
     """The colour loop of `gen_mesh` (`reconstruction.py:58-70`) as rounds: [(first_span, spans_per_rank)].  In a round,
     rank r computes the `spans_per_rank` consecutive calc_normal calls that start at `first_span + r * spans_per_rank`, so
     the ranks' results laid side by side ARE the colour rows of spans [first_span, first_span + ws * spans_per_rank) in
     vertex order (every span but the very last has exactly `interval` rows): one all-gather per round extends the PREFIX
     of finished colours, which is what the OBJ writer's `ready(upto)` takes.  Every rank ends with ceil(n_spans / ws)
-    calls or fewer; a round is at most `per_call_cap` calls per rank (ten 50 000-vertex calls = 2.0 M point rows = one
-    batch of launches of the workspace) and there are `target_rounds` rounds where the mesh allows, so the last exchange +
-    file block is a quarter of the loop at most.  One rank: plain groups of at most ten calls."""
-    per_rank = -(-n_spans // ws)
-    rounds = max(min(target_rounds, per_rank), -(-per_rank // per_call_cap), 1)
+    calls or fewer.  A round is at most `per_call_cap` calls per rank (ten 50 000-vertex calls = 2.0 M point rows = one
+    batch of launches of the workspace) and the rounds TAPER - each takes half of what is left, down to a single call per
+    rank - because what remains to be done once the GPU has finished is the last round's exchange, host copy and vertex
+    lines: [10, 10, ..., 3, 2, 1] calls per rank instead of a last round as large as the first."""
+    left = -(-n_spans // ws)
     out, base = [], 0
-    for k in range(rounds):
-        m = per_rank // rounds + (1 if k < per_rank % rounds else 0)
-        if base >= n_spans or m == 0:
-            break
+    while left > 0 and base < n_spans:
+        m = min(per_call_cap, max(1, -(-left // 2)))
         out.append((base, m))
         base += ws * m
+        left -= m
     return out
 
 

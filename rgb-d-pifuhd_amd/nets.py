@@ -110,11 +110,17 @@ _ENC_NORM = {('batch', False): 0, ('batch', True): 1, ('group', False): 2, ('gro
 
 
 def _push_encoder_params(ctx, sd, prefix):
-    """Register every floating-point parameter / buffer of an encoder with the context (HOST fp32 copies)."""
+    """Register every floating-point parameter / buffer of an encoder with the context: convolution weights that live on the
+    context's device go across as device pointers (no host round trip of the 1.5 GB), everything else as HOST fp32 copies."""
     for key, t in sd.items():
         if not (key.startswith('image_filter.') or key.startswith('netF.') or key.startswith('netB.')):
             continue
         if not t.dtype.is_floating_point:
+            continue
+        if t.dim() == 4 and t.is_cuda and t.device == ctx.device:
+            d = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * 4)(*d.shape)
+            _lib.call('pifu_enc_set_param_device', ctx.h, (prefix + key).encode(), _ptr(d), shape, 4, _stream_ptr(ctx.device))
             continue
         a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
         shape = (C.c_int64 * max(1, a.ndim))(*a.shape)

@@ -244,7 +244,27 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         side, cur = copy_stream(dev), torch.cuda.current_stream(dev)
         wsx = ws if exchange else 1
         rounds = pdist.colour_rounds(len(spans), wsx) if _pipeline else [(0, -(-len(spans) // wsx))]
-        obj, done = None, []
+        obj, done, laid_out = None, [], False
+        color = np.zeros((n_verts, 3)) if wants_result else None  # the float64 colour array gen_mesh returns
+
+        def drain(block):
+            """Hand the rounds whose colours have landed to the OBJ writer (it formats and writes their vertex lines on its own
+            threads while the GPU computes the next round) and to the float64 result; `block`: wait for every round."""
+            nonlocal laid_out
+            if obj is not None and not laid_out and (block or host_copies.verts is None or host_copies.verts.query()):
+                host_copies.wait_verts()
+                obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
+                laid_out = True
+            while done and (block or done[0][2].query()):
+                if obj is not None and not laid_out:
+                    break
+                L, R, ev = done.pop(0)
+                ev.synchronize()
+                if obj is not None:
+                    obj.ready(R)                                  # this round's vertex lines are formatted and written now
+                if color is not None:
+                    color[L:R] = host_np[L:R]
+
         for (base, m) in rounds:
             mine, (L, R), slot = pdist.round_rows(spans, base, m, wsx, rank, interval)
             col_d = normals_of(*mine).contiguous() if mine is not None else None
@@ -271,18 +291,12 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
             if obj is None and rank == 0:
                 host_copies.wait_faces()
                 obj = ObjFile(save_path, faces)                   # the face lines are formatted while the colours are computed
-        color = None
+            # rounds that have landed meanwhile go to the writer now (with a transport whose collectives block the host -
+            # gloo - this is where the file keeps up with the loop; with RCCL the loop is queued long before the first lands)
+            drain(False)
         if wants_result:
             host_copies.wait_verts()
-            color = np.zeros((n_verts, 3))                        # the float64 colour array gen_mesh returns
-        if obj is not None:
-            obj.layout(np.ascontiguousarray(verts, dtype=np.float64), host_np)      # every file offset follows from the positions
-        for (L, R, ev) in done:
-            ev.synchronize()
-            if obj is not None:
-                obj.ready(R)                                      # this round's vertex lines are formatted and written now
-            if color is not None:
-                color[L:R] = host_np[L:R]                         # while the GPU computes the next round
+        drain(True)
         t4 = time.perf_counter()                                  # the last colours are on the host: the GPU phase is over
         if obj is not None:
             obj.finish()

@@ -125,7 +125,7 @@ def _rounds_worker(rank, ws, port, n_verts, interval, q):
     seen, prefix = [], []
     out = torch.zeros(n_verts, 3)
     pdist.stats_begin()
-    for (base, m) in pdist.colour_rounds(len(spans), ws, per_call_cap=3, target_rounds=2):
+    for (base, m) in pdist.colour_rounds(len(spans), ws, per_call_cap=3):
         mine, (L, R), slot = pdist.round_rows(spans, base, m, ws, rank, interval)
         local = torch.zeros(slot, 3)
         if mine is not None:
@@ -187,8 +187,10 @@ def test_colour_rounds_shapes():
             assert all(b[0] == a[0] + ws * a[1] for a, b in zip(r, r[1:]))           # rounds tile the span list
             assert r[-1][0] < n <= r[-1][0] + ws * r[-1][1]
             assert sum(m for (_, m) in r) == -(-n // ws) or r[-1][0] + ws * r[-1][1] >= n
-    assert colour_rounds(86, 1) == [(0, 10), (10, 10), (20, 10), (30, 10), (40, 10), (50, 9), (59, 9), (68, 9), (77, 9)]
-    assert [m for (_, m) in colour_rounds(86, 8)] == [3, 3, 3, 2]
+    # the rounds taper: what is left once the GPU has finished is the last round's exchange + vertex lines
+    assert [m for (_, m) in colour_rounds(86, 1)] == [10] * 7 + [8, 4, 2, 1, 1]
+    assert [m for (_, m) in colour_rounds(86, 2)] == [10, 10, 10, 7, 3, 2, 1]
+    assert [m for (_, m) in colour_rounds(86, 8)] == [6, 3, 1, 1]
 
 
 def test_slab_planes_cover_the_cell_layers_once():

@@ -275,7 +275,7 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     oss = gm['one_subject_sharded']
     assert oss['world'] == 2 and oss['result_on'] == 'rank0' and oss['collectives'] >= 2 and oss['collective_bytes'] > 0
     assert oss['collective_s'] >= 0 and oss['collective_s_max_over_ranks'] >= 0 and oss['colour_rounds'] >= 1
-    assert gm['independent_subjects']['warmed'] is True and gm['host_threads_per_rank'] >= 2
+    assert gm['independent_subjects']['warmed'] is True and gm['host_threads_per_rank_independent_subjects'] >= 2
     assert 'error' not in gm['config5_1024'], gm['config5_1024']
     assert gm['config5_1024']['mesh_identical_on_all_ranks'] and gm['config5_1024']['n_verts'] > 0
 

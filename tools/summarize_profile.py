@@ -27,9 +27,18 @@ def is_col(name):
 # (1) kernel stats
 stats = sorted(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime, reverse=True)
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
+cmd_file = os.path.join(src, 'trace_command.txt')
+command = open(cmd_file).read().strip() if os.path.exists(cmd_file) else 'python bench.py ... (tools/profile_gpu.sh)'
+gemm_rows = [r for r in rows if 'k_mlp_gemm' in r['Name']]
+mix = ''
+if gemm_rows:
+    calls = sum(int(r['Calls']) for r in gemm_rows)
+    mix = (f'# k_mlp_gemm_tri launch mix of this trace: {calls} launches = (1 warm-up + 2 timed) passes over the 256^3 lattice in 8 '
+           f'batches x 7 layer launches (= 168, the headline mix, chunk 5000) + {calls - 168} launches of the set-up call '
+           f'(calibrate_occupancy_bias on a 64^3 lattice, pixel-table-free); no other leg of bench.py runs in this trace\n')
 with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 '
-            '--no-cpu-baseline --no-genmesh   (MI355X, 1 GPU)\n')
+    f.write(f'# rocprofv3 --kernel-trace --stats -- {command}   (MI355X, 1 GPU)\n')
+    f.write(mix)
     f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
     for r in rows[:16]:
         f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
