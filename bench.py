@@ -255,6 +255,7 @@ def main():
                     help='functional check, never a measurement: initialise the process group (backend nccl = RCCL) even with ONE '
                          'rank and run every collective of the sharded path (all-gather of the field, of the colours, barrier)')
     ap.add_argument('--no-chunk100k', action='store_true', help='skip the extra pass in 100 000-point chunks')
+    ap.add_argument('--no-calc-normal-leg', action='store_true', help='skip the calc_normal measurement (pixel tables against per-point GEMMs)')
     ap.add_argument('--no-encoder-leg', action='store_true', help='skip the timed encoder passes (roofline_secondary: encoders)')
     ap.add_argument('--no-canonical', action='store_true', help='skip the extra canonical per-point pass (no column sharing)')
     ap.add_argument('--canonical-steps', type=int, default=2)
@@ -533,7 +534,7 @@ def main():
     # ---- the colour loop's kernel path on its own: calc_normal on seeded vertices in gen_mesh's 50 000-vertex calls (each one
     # GroupNorm batch of 200 000 point rows), through the pixel tables (default for calls of this size) and through the
     # per-point GEMMs (pifu_set_pixel_tables(ctx, 0): every FLOP of a lean query executed), alternating
-    if world == 1 and not args.no_canonical:
+    if world == 1 and not args.no_canonical and not args.no_calc_normal_leg:
         try:
             nv = 500000
             gv = torch.Generator().manual_seed(5)

@@ -14,7 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $BE
 SMALL="bench.py --steps 1 --warmup 0 --no-canonical --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass --no-chunk100k --no-encoder-leg"
 # the canonical per-point pass launches the batch-sized k_sample: its counters come from two extra passes, so that the GEMM
 # averages above stay over the headline launch mix
-CANON="bench.py --steps 1 --warmup 0 --canonical-steps 1 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass --no-chunk100k --no-encoder-leg"
+# (without the calc_normal leg: its per-point pass launches k_sample on RANDOM vertices, whose gathers miss the L2 - the figure
+# wanted here is the lattice pass's)
+CANON="bench.py --steps 1 --warmup 0 --canonical-steps 1 --no-cpu-baseline --no-genmesh --no-split-precision --no-lean-pass --no-chunk100k --no-encoder-leg --no-calc-normal-leg"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $SMALL > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $SMALL > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $SMALL > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err
