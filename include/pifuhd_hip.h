@@ -9,7 +9,9 @@
  *   - the CALLER owns every buffer (device pointers unless a parameter says "host"); the library owns
  *     only the opaque context (packed weights, NHWC feature maps, workspaces);
  *   - all kernels are enqueued on the caller's stream (a hipStream_t passed as void*); only the calls
- *     documented as "synchronises" wait for the device;
+ *     documented as "synchronises" wait for the device; a context serves one call at a time (it is not
+ *     re-entrant: workspaces, feature maps and tables are shared), but the calls may come on different streams:
+ *     an entry point called with another stream than the previous call makes it wait for that call's work;
  *   - fp32 network arithmetic (exact-fp32 MFMA), float64 grid bookkeeping, as in the reference.
  */
 #ifndef PIFUHD_HIP_H
@@ -82,7 +84,8 @@ enum {
  *   4: round 5 - the automatic pixel-table threshold follows the coarse map (calls of at least max(16 384, H * W) points: the
  *      same as before for the 128^2 map, later for larger maps); pifu_set_workspace_limit is a hard bound of the query arena (no allocation slack);
  *      pifu_arena_bytes, pifu_set_host_threads, pifu_enc_set_param_device and the pifu_comm_* / pifu_allgather_* calls added;
- *      a context may be used from several streams: the pixel table is ordered against its builder and its readers by events. */
+ *      a context is still used by ONE call at a time, but consecutive calls may be enqueued on different streams without the
+ *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call. */
 #define PIFU_ABI_VERSION 4
 const char *pifu_last_error(void);
 int pifu_abi_version(void);

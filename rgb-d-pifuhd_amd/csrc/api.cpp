@@ -148,13 +148,28 @@ extern "C" int pifu_ctx_destroy(pifu_ctx *ctx)
     if (ctx->tile_ctr) (void)hipFree(ctx->tile_ctr);
     if (ctx->debug_buf) (void)hipFree(ctx->debug_buf);
 #endif
-    if (ctx->pix.built) (void)hipEventDestroy(ctx->pix.built);
-    for (auto &kv : ctx->pix.readers) (void)hipEventDestroy(kv.second);
+    if (ctx->use_event) (void)hipEventDestroy(ctx->use_event);
     if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
     if (ctx->ident_scale) (void)hipFree(ctx->ident_scale);
     if (ctx->ident_shift) (void)hipFree(ctx->ident_shift);
     delete ctx;
     return PIFU_OK;
+}
+
+int pifu_use_begin(pifu_ctx *ctx, hipStream_t st)
+{
+    if (!ctx) return PIFU_OK;                 // the entry point's own argument check reports it
+    PIFU_HIP(hipSetDevice(ctx->device));
+    if (!ctx->use_event) PIFU_HIP(hipEventCreateWithFlags(&ctx->use_event, hipEventDisableTiming));
+    if (ctx->use_recorded && ctx->use_stream != st) PIFU_HIP(hipStreamWaitEvent(st, ctx->use_event, 0));
+    return PIFU_OK;
+}
+
+void pifu_use_end(pifu_ctx *ctx, hipStream_t st)
+{
+    if (!ctx || !ctx->use_event) return;
+    if (hipEventRecord(ctx->use_event, st) == hipSuccess) { ctx->use_stream = st; ctx->use_recorded = true; }
+    else (void)hipGetLastError();
 }
 
 int pifu_prof_begin(pifu_ctx *ctx, int slot, hipStream_t st, hipEvent_t *stop)

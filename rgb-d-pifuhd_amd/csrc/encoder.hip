@@ -1479,6 +1479,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     PIFU_REQUIRE(H % 16 == 0 && W % 16 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_coarse: H, W must be multiples of 16");
     PIFU_REQUIRE((!use_front || nmlF) && (!use_back || nmlB), PIFU_ERR_INVALID, "pifu_filter_coarse: normal-map output buffers missing");
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_coarse: bad norm / hg_dim");
+    PIFU_USE(ctx, stream);
     const bool all_stacks = (flags & PIFU_ENC_ALL_STACKS) != 0, defer = (flags & PIFU_ENC_DEFER_JOIN) != 0;
     EncState &S = state_of(ctx);
     hipStream_t st = (hipStream_t)stream;
@@ -1566,6 +1567,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     PIFU_REQUIRE(ctx && img_nchw, PIFU_ERR_INVALID, "pifu_filter_fine: null argument");
     PIFU_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 32 && W >= 32, PIFU_ERR_INVALID, "pifu_filter_fine: H, W must be multiples of 8");
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_fine: bad norm / hg_dim");
+    PIFU_USE(ctx, stream);
     EncState &S = state_of(ctx);
     const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
     int rc = begin(ctx, S, 0, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);

@@ -112,6 +112,7 @@ extern "C" int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, i
 {
     PIFU_REQUIRE(ctx && feat_nchw && uv && out, PIFU_ERR_INVALID, "pifu_index: null argument");
     PIFU_REQUIRE(C > 0 && H > 0 && W > 0 && n >= 0, PIFU_ERR_INVALID, "pifu_index: bad shape C=%d H=%d W=%d n=%lld", C, H, W, (long long)n);
+    PIFU_USE(ctx, stream);
     if (n == 0) return PIFU_OK;
     PIFU_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat_nchw, C, H, W, uv, n, out);
@@ -125,6 +126,7 @@ extern "C" int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, i
     PIFU_REQUIRE(ctx && bgr && rect && out, PIFU_ERR_INVALID, "pifu_preprocess_image: null argument");
     PIFU_REQUIRE(H > 0 && W > 0 && size > 0 && rect[2] > 0 && rect[3] > 0, PIFU_ERR_INVALID,
                  "pifu_preprocess_image: bad shape H=%d W=%d size=%d rect=(%d,%d,%d,%d)", H, W, size, rect[0], rect[1], rect[2], rect[3]);
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     ResizeArgs a;
     a.src = bgr; a.H = H; a.W = W;

@@ -71,6 +71,7 @@ extern "C" int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, 
 {
     PIFU_REQUIRE(ctx && pred && gt && out, PIFU_ERR_INVALID, "pifu_bce_loss: null argument");
     PIFU_REQUIRE(batch > 0 && n > 0, PIFU_ERR_INVALID, "pifu_bce_loss: empty input (the reference's mean() would be nan)");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     int rc = pifu_ensure(ctx->misc, LOSS_BLOCKS * sizeof(double));
     if (rc) return rc;

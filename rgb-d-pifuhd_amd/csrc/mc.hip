@@ -732,6 +732,7 @@ extern "C" int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n
     PIFU_REQUIRE(ctx && volume && nverts && nfaces, PIFU_ERR_INVALID, "pifu_mc_count: null argument");
     PIFU_REQUIRE(dtype == 0 || dtype == 1, PIFU_ERR_INVALID, "pifu_mc_count: dtype must be 0 (f32) or 1 (f64)");
     PIFU_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, PIFU_ERR_INVALID, "Input array must be at least 2x2x2.");
+    PIFU_USE(ctx, stream);
     uint64_t nv, nf;
     float lo, hi;
     int rc = mc_count_impl(ctx, volume, dtype, n0, n1, n2, level, 0, &nv, &nf, &lo, &hi, (hipStream_t)stream);
@@ -756,6 +757,7 @@ extern "C" int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_st
 {
     PIFU_REQUIRE(ctx && verts && faces, PIFU_ERR_INVALID, "pifu_mc_emit: null argument");
     PIFU_REQUIRE(ctx->mc.valid && !ctx->mc.slab, PIFU_ERR_STATE, "pifu_mc_emit: call pifu_mc_count first");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const McState &m = ctx->mc;
@@ -781,6 +783,7 @@ extern "C" int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, in
     PIFU_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2 && z_first >= 0, PIFU_ERR_INVALID,
                  "pifu_mc_slab_count: a slab needs at least 2 node planes of at least 2x2 nodes (got %d x %d x %d at plane %d)", n0, n1,
                  n2, z_first);
+    PIFU_USE(ctx, stream);
     uint64_t nv, nf;
     int rc = mc_count_impl(ctx, slab, dtype, n0, n1, n2, level, z_first, &nv, &nf, vmin, vmax, (hipStream_t)stream);
     if (rc) return rc;
@@ -795,6 +798,7 @@ extern "C" int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base
 {
     PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_mc_slab_verts: null context");
     PIFU_REQUIRE(ctx->mc.valid && ctx->mc.slab, PIFU_ERR_STATE, "pifu_mc_slab_verts: call pifu_mc_slab_count first");
+    PIFU_USE(ctx, stream);
     const McState &m = ctx->mc;
     PIFU_REQUIRE(verts || m.nverts == 0, PIFU_ERR_INVALID, "pifu_mc_slab_verts: null vertex array for %lld vertices", (long long)m.nverts);
     PIFU_REQUIRE(vert_base >= 0 && vert_base + m.nverts < ((int64_t)1 << 31), PIFU_ERR_INVALID,
@@ -818,6 +822,7 @@ extern "C" int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *
     PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_mc_slab_faces: null context");
     PIFU_REQUIRE(ctx->mc.valid && ctx->mc.slab && ctx->mc.verts_done, PIFU_ERR_STATE,
                  "pifu_mc_slab_faces: call pifu_mc_slab_count and pifu_mc_slab_verts first");
+    PIFU_USE(ctx, stream);
     const McState &m = ctx->mc;
     PIFU_REQUIRE(faces || m.nfaces == 0, PIFU_ERR_INVALID, "pifu_mc_slab_faces: null face array for %lld faces", (long long)m.nfaces);
     PIFU_REQUIRE((m.zoff == 0) == (halo_in == nullptr), PIFU_ERR_INVALID,
@@ -854,6 +859,7 @@ __global__ void k_transform_verts(const float *verts, int64_t n, const Mat34 t, 
 extern "C" int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && mat && (n == 0 || (verts && out)) && n >= 0, PIFU_ERR_INVALID, "pifu_transform_verts: bad argument");
+    PIFU_USE(ctx, stream);
     if (n == 0) return PIFU_OK;
     PIFU_HIP(hipSetDevice(ctx->device));
     Mat34 t;

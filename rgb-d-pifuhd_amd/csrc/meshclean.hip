@@ -215,6 +215,7 @@ extern "C" int pifu_face_components(pifu_ctx *ctx, const int32_t *faces, int64_t
 {
     PIFU_REQUIRE(ctx && faces && label && open_edge, PIFU_ERR_INVALID, "pifu_face_components: null argument");
     PIFU_REQUIRE(nfaces > 0 && nfaces < ((int64_t)1 << 29), PIFU_ERR_INVALID, "pifu_face_components: 0 < nfaces < 2^29");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     int64_t cap = 1024;
@@ -242,6 +243,7 @@ extern "C" int pifu_esti_color(pifu_ctx *ctx, const float *xyz, int64_t n, uint1
 {
     PIFU_REQUIRE(ctx && xyz && color, PIFU_ERR_INVALID, "pifu_esti_color: null argument");
     PIFU_REQUIRE(n > 0 && n < ((int64_t)1 << 31), PIFU_ERR_INVALID, "pifu_esti_color: 0 < n < 2^31");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     // the selection lists (back vertices, silhouette vertices sorted by (y, x, index)) are built on the host from one

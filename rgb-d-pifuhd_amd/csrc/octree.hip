@@ -180,6 +180,7 @@ int octree_select_impl(pifu_ctx *ctx, int R, int reso, const uint8_t *notproc, i
 extern "C" int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *notprocessed, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && sdf && notprocessed && R >= 2, PIFU_ERR_INVALID, "pifu_octree_begin: bad argument");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     ctx->sel.valid = false;
     const int64_t n = (int64_t)R * R * R;
@@ -192,6 +193,7 @@ extern "C" int pifu_octree_select(pifu_ctx *ctx, int R, int reso, const uint8_t 
                                   int64_t cap, int64_t *count_host, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && notprocessed && count_host && R >= 2 && reso >= 1, PIFU_ERR_INVALID, "pifu_octree_select: bad argument");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     return octree_select_impl(ctx, R, reso, notprocessed, index_out, cap, count_host, index_out == nullptr, (hipStream_t)stream);
 }
@@ -201,6 +203,7 @@ extern "C" int pifu_octree_commit(pifu_ctx *ctx, int R, int reso, double thresho
 {
     PIFU_REQUIRE(ctx && sdf && notprocessed && R >= 2 && reso >= 1 && count >= 0, PIFU_ERR_INVALID, "pifu_octree_commit: bad argument");
     PIFU_REQUIRE(count == 0 || (index && values), PIFU_ERR_INVALID, "pifu_octree_commit: null index/values");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     ctx->sel.valid = false;
     hipStream_t st = (hipStream_t)stream;
@@ -232,6 +235,7 @@ extern "C" int pifu_eval_grid(pifu_ctx *ctx, int R, const double *calib_inv, con
                               int64_t *n_evaluated, pifu_stream stream)
 {
     PIFU_REQUIRE(ctx && calib_inv && calib && sdf && R >= 2 && chunk > 0, PIFU_ERR_INVALID, "pifu_eval_grid: bad argument");
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int32_t res[3] = {R, R, R};

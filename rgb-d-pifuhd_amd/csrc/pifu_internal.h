@@ -125,13 +125,14 @@ struct pifu_ctx {
     // pixel tables of explicit point lists (query.hip "Pixel tables"): G = W_feat * F over the pixels of the coarse map
     int pix_mode = 1;                     // pifu_set_pixel_tables: 0 off, 1 from PIFU_PIXEL_TABLE_MIN_POINTS points on, 2 always
     DevBuf pix_arena;
-    // `built` orders every reader's stream behind the table's construction; `readers` holds one event per stream that has
-    // blended from the table (recorded after its last expand kernel) - a rebuild in place waits for all of them
-    struct PixState {
-        bool valid = false; const float *feat = nullptr; int H = 0, W = 0, C = 0, precision = 0, ldg = 0;
-        hipEvent_t built = nullptr;
-        std::map<hipStream_t, hipEvent_t> readers;
-    } pix;
+    struct PixState { bool valid = false; const float *feat = nullptr; int H = 0, W = 0, C = 0, precision = 0, ldg = 0; } pix;
+    // Cross-stream ordering of the context's shared state (workspace arenas, feature maps, column / pixel tables, packed
+    // weights): every entry point that enqueues work records `use_event` on its stream when it returns, and an entry point
+    // called with ANOTHER stream makes that stream wait for it first (PIFU_USE).  A context is still used by one call at a
+    // time, but the calls may come on different streams without the caller synchronising them.
+    hipEvent_t use_event = nullptr;
+    hipStream_t use_stream = nullptr;
+    bool use_recorded = false;
     // small persistent device scratch (scan totals etc.)
     DevBuf misc;
     void *pinned = nullptr;   // 256 B of pinned host memory for count read-backs
@@ -168,6 +169,21 @@ int pifu_prof_end(pifu_ctx *ctx, int slot, hipEvent_t stop, double work, hipStre
 
 // grow-only hipMalloc (synchronises when it grows); `exact`: no slack on top of `bytes` (arenas with a caller-set bound)
 int pifu_ensure(DevBuf &b, size_t bytes, bool exact = false);
+// PIFU_USE(ctx, stream) at the top of an entry point: `stream` waits for the previous call's work if that was enqueued on
+// another stream; when the entry point returns (any path) the event is recorded on `stream`
+int pifu_use_begin(pifu_ctx *ctx, hipStream_t st);
+void pifu_use_end(pifu_ctx *ctx, hipStream_t st);
+struct PifuUse {
+    pifu_ctx *c; hipStream_t s;
+    PifuUse(pifu_ctx *c_, hipStream_t s_) : c(c_), s(s_) {}
+    ~PifuUse() { pifu_use_end(c, s); }
+};
+#define PIFU_USE(ctx, st)                                         \
+    {                                                             \
+        const int use_rc_ = pifu_use_begin((ctx), (hipStream_t)(st)); \
+        if (use_rc_) return use_rc_;                              \
+    }                                                             \
+    PifuUse pifu_use_guard_((ctx), (hipStream_t)(st))
 // encoder.hip: make `st` wait for a coarse hourglass that pifu_filter_coarse(PIFU_ENC_DEFER_JOIN) left running
 int pifu_enc_join(pifu_ctx *ctx, hipStream_t st);
 

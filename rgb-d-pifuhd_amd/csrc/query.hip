@@ -1347,6 +1347,7 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
     PIFU_REQUIRE(level == 0 || level == 1, PIFU_ERR_INVALID, "pifu_set_features: level must be 0 or 1");
     PIFU_REQUIRE(C > 0 && C % 4 == 0 && H > 1 && W > 1, PIFU_ERR_INVALID,
                  "pifu_set_features: need C %% 4 == 0 and H, W > 1 (got C=%d H=%d W=%d)", C, H, W);
+    PIFU_USE(ctx, stream);
     PIFU_HIP(hipSetDevice(ctx->device));
     {
         const int rc = pifu_enc_join(ctx, (hipStream_t)stream);      // a deferred coarse hourglass may still be writing its map
@@ -1695,14 +1696,11 @@ static int build_pixel_table(pifu_ctx *ctx, hipStream_t st)
     const Mlp &m = ctx->mlp[0];
     const FeatMap &f = ctx->feat[0];
     pifu_ctx::PixState &px = ctx->pix;
-    if (!px.built) PIFU_HIP(hipEventCreateWithFlags(&px.built, hipEventDisableTiming));
+    // (a table another stream enqueued a moment ago, or one other streams are still blending from while it is rebuilt in place
+    // for a new map: the calls themselves are ordered across streams, PIFU_USE)
     if (px.valid && px.feat == f.nhwc && px.H == f.H && px.W == f.W && px.C == f.C && px.precision == ctx->precision &&
-        px.ldg == m.col_rows) {
-        PIFU_HIP(hipStreamWaitEvent(st, px.built, 0));      // another stream may have enqueued the construction a moment ago
+        px.ldg == m.col_rows)
         return PIFU_OK;
-    }
-    // rebuilt in place: every stream that blended from the previous table must have finished with it
-    for (auto &kv : px.readers) PIFU_HIP(hipStreamWaitEvent(st, kv.second, 0));
     const int64_t hw = (int64_t)f.H * f.W, hw_pad = round_up(hw, BM);
     const size_t gbytes = ((size_t)hw_pad * m.col_rows * sizeof(float) + 255) & ~(size_t)255;
     const size_t fbytes = hw != hw_pad ? (size_t)hw_pad * f.Cpad * sizeof(float) : 0;     // row tiles must not read past the map
@@ -1728,7 +1726,6 @@ static int build_pixel_table(pifu_ctx *ctx, hipStream_t st)
     for (int i = 0; i < m.nlayers; ++i) if (m.layer[i].cin_feat) real_rows += m.layer[i].cout;
     rc = run_gemm(ctx, a, 2.0 * hw * real_rows * (double)(m.dims[0] - 1), st);
     if (rc) return rc;
-    PIFU_HIP(hipEventRecord(px.built, st));
     px.valid = true; px.feat = f.nhwc; px.H = f.H; px.W = f.W; px.C = f.C; px.precision = ctx->precision; px.ldg = m.col_rows;
     return PIFU_OK;
 }
@@ -1877,6 +1874,7 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "null context");
     PIFU_REQUIRE(n >= 0 && chunk > 0, PIFU_ERR_INVALID, "query: need n >= 0 and chunk > 0");
     if (n == 0) return PIFU_OK;
+    PIFU_USE(ctx, st);
     {
         const int rc = pifu_enc_join(ctx, st);      // a coarse hourglass left running by pifu_filter_coarse(PIFU_ENC_DEFER_JOIN)
         if (rc) return rc;
@@ -2089,11 +2087,6 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                               fine_out ? fine_out + pt0 : nullptr, ctx->mlp[1].nlayers, st);
             if (rc != PIFU_OK) return rc;
         }
-    }
-    if (pixmode) {      // this stream has read the pixel table up to here: a rebuild on another stream waits for it
-        hipEvent_t &ev = ctx->pix.readers[st];
-        if (!ev) PIFU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        PIFU_HIP(hipEventRecord(ev, st));
     }
     PIFU_HIP(hipGetLastError());
     return PIFU_OK;

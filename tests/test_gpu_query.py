@@ -616,6 +616,53 @@ def test_pixel_tables_follow_the_feature_map_and_the_flags():
         _pixel_tables(netMR, _lib.PIX_AUTO)
 
 
+def test_calls_on_different_streams_are_ordered_by_the_context():
+    """One context, consecutive calls on DIFFERENT streams with no synchronisation between them (the ABI's contract since
+    version 4): a new coarse map installed on stream A, a pixel-table query on stream B (it builds the table of the new map
+    there), the same query on stream C right behind it, a per-point query on A again - the workspace arena, the feature map
+    and the pixel table are shared by all of them.  Every result must equal the one of the same calls on a single
+    synchronised stream."""
+    import ctypes as C
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr
+    netG, netMR, *_ = _build()
+    cal = np.ascontiguousarray(calib_tensor()[0].numpy())
+    h = netMR._ctx.h
+    n = _lib.PIXEL_TABLE_MIN_POINTS + 3000
+    pts = seeded_points(41, n, lim=1.05).cuda().contiguous()
+
+    def run(stream, flags):
+        out = torch.empty(n, device='cuda')
+        _lib.call('pifu_query', h, _ptr(pts), n, cal.ctypes.data_as(C.c_void_p), 5000, flags, _ptr(out), None, None,
+                  C.c_void_p(stream.cuda_stream))
+        return out
+
+    def install(stream, fc_dev):
+        _lib.call('pifu_set_features', h, _lib.LEVEL_COARSE, _ptr(fc_dev), fc_dev.shape[1], fc_dev.shape[2], fc_dev.shape[3],
+                  C.c_void_p(stream.cuda_stream))
+    maps = [seeded_features(50 + k)[0].cuda().contiguous() for k in range(4)]
+    main = torch.cuda.current_stream()
+    want = []
+    for fc_dev in maps:                                         # the reference run: one stream, synchronised
+        install(main, fc_dev)
+        a, b = run(main, 0), run(main, _lib.Q_NO_COLUMN_SHARING)
+        torch.cuda.synchronize()
+        want.append((a.clone(), b.clone()))
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for fc_dev in maps:                                         # no synchronisation anywhere in this loop
+        install(sa, fc_dev)
+        g1 = run(sb, 0)
+        g2 = run(sc, 0)
+        g3 = run(sa, _lib.Q_NO_COLUMN_SHARING)
+        got.append((g1, g2, g3))
+    torch.cuda.synchronize()
+    for (a, b), (g1, g2, g3) in zip(want, got):
+        assert torch.equal(g1, a) and torch.equal(g2, a) and torch.equal(g3, b)
+    assert not torch.equal(want[0][0], want[1][0])
+
+
 def test_calc_normal_with_pixel_tables():
     """calc_normal's [p, p+dx, p+dy, p+dz] rows through the pixel tables against the per-point GEMM path: the 4n
     occupancies by value, the normals by angle (forward differences over 1e-3 amplify fp32 rounding ~1e3 x)."""
