@@ -64,6 +64,11 @@ enum {
 enum {
     PIFU_ENC_ALL_STACKS = 1,               /* feat_nchw receives every stack's output (the module in train mode keeps the
                                               whole list, PIFuNetwNML.py:94-97) instead of the last one */
+    PIFU_ENC_NORMALS_ONLY = 4,             /* run the enabled normal nets (use_front / use_back) and stop: no hourglass, the
+                                              coarse feature map stays as it is */
+    PIFU_ENC_NORMALS_GIVEN = 8,            /* nmlF / nmlB are INPUTS (device NCHW [1][3][H][W], e.g. computed by other ranks):
+                                              the normal nets are skipped, the hourglass runs on cat[img, nmlF, nmlB].  The
+                                              two halves of PIFuNetwNML.filter for callers that deal them to different GPUs */
     PIFU_ENC_DEFER_JOIN = 2                /* return while the coarse hourglass is still running on a stream of the library:
                                               pifu_filter_fine - which reads the normal maps, not the coarse features -
                                               then runs beside it.  The caller's stream is made to wait for the hourglass by
@@ -83,7 +88,8 @@ enum {
  *      pifu_set_pixel_tables, pifu_set_workspace_limit added.
  *   4: round 5 - the automatic pixel-table threshold follows the coarse map (calls of at least max(16 384, H * W) points: the
  *      same as before for the 128^2 map, later for larger maps); pifu_set_workspace_limit is a hard bound of the query arena (no allocation slack);
- *      pifu_arena_bytes, pifu_set_host_threads, pifu_enc_set_param_device and the pifu_comm_* / pifu_allgather_* calls added;
+ *      pifu_arena_bytes, pifu_set_host_threads, pifu_enc_set_param_device, the PIFU_ENC_NORMALS_* flags and the pifu_comm_* /
+ *      pifu_allgather_* calls added;
  *      a context is still used by ONE call at a time, but consecutive calls may be enqueued on different streams without the
  *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call. */
 #define PIFU_ABI_VERSION 4

@@ -1481,6 +1481,10 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_coarse: bad norm / hg_dim");
     PIFU_USE(ctx, stream);
     const bool all_stacks = (flags & PIFU_ENC_ALL_STACKS) != 0, defer = (flags & PIFU_ENC_DEFER_JOIN) != 0;
+    // the two halves of the call on their own (a rank of a sharded gen_mesh runs one normal net, or the hourglass on normal
+    // maps another rank computed): NORMALS_ONLY stops after the enabled normal nets, NORMALS_GIVEN reads nmlF / nmlB as inputs
+    const bool normals_only = (flags & PIFU_ENC_NORMALS_ONLY) != 0, normals_given = (flags & PIFU_ENC_NORMALS_GIVEN) != 0;
+    PIFU_REQUIRE(!(normals_only && normals_given), PIFU_ERR_INVALID, "pifu_filter_coarse: NORMALS_ONLY and NORMALS_GIVEN exclude each other");
     EncState &S = state_of(ctx);
     hipStream_t st = (hipStream_t)stream;
     const size_t px = (size_t)H * W;
@@ -1489,7 +1493,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     try {
         // the two normal nets read the same packed image and nothing of each other: netF on the caller's stream (lane 0),
         // netB beside it on lane 1
-        if (use_front || use_back) {
+        if ((use_front || use_back) && !normals_given) {
             rc = begin(ctx, S, 0, px * 4 * (size_t)1000 + ((size_t)320 << 20), st);
             if (rc) return rc;
             Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W);
@@ -1510,6 +1514,11 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
             } else {
                 global_generator(S, "netB", in, nmlB);
             }
+        }
+        if (normals_only) {
+            S.cur = &S.lanes[0];
+            PIFU_HIP(hipGetLastError());
+            return PIFU_OK;
         }
         // the hourglass filter runs on lane 2: with PIFU_ENC_DEFER_JOIN the call returns while it is still running - the fine
         // level (pifu_filter_fine, lane 0) does not read its result and fills the chip beside it - otherwise the caller's

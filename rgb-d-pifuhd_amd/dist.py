@@ -279,6 +279,58 @@ def _timed(fn, nbytes, device):
     return out
 
 
+def _broadcast(t, src, group=None):
+    import torch.distributed as dist
+    _timed(lambda: dist.broadcast(t, src=src, group=group), t.numel() * t.element_size(), t.device)
+
+
+def filter_sharded(net, coarse_image, fine_image, group=None):
+    """`filter_global` + `filter_local` of ONE subject dealt out over the ranks (every rank calls it with the same images;
+    world size >= 2, both normal nets present, netG in eval mode - the `recon()` configuration - else the plain replicated
+    calls): the two normal nets (`networks.py:131-207`, 435 GFLOP each) run on ranks 0 and 1 at the same time, their maps
+    are broadcast (2 x 3 MB), then rank 0 runs the fine HGFilter (920 GFLOP) while rank 1 runs the coarse one (212 GFLOP)
+    and the two feature maps are broadcast (2 x 16.8 MB at 1024 px) and installed on the other ranks (`pifu_set_features`).
+    The chain netF -> fine HGFilter is what remains on the critical path (~15 ms instead of the ~21 ms of a whole pass on
+    every rank); same kernels on the same inputs: every rank ends with bit-identical maps."""
+    rank, ws = world()
+    g = net.netG
+    split = (collective_active() and ws >= 2 and g.netF is not None and g.netB is not None and not g.training
+             and not (net.training and int(net.opt.num_stack) > 1))
+    if not split:
+        net.filter_global(coarse_image)
+        net.filter_local(fine_image[:, None])
+        return False
+    dev = net.device
+    h, w = coarse_image.shape[2:]
+    # (1) one normal net per rank (ranks 0 and 1), the maps to everybody
+    if rank == 0:
+        g.filter(coarse_image, _part='F')
+    elif rank == 1:
+        g.filter(coarse_image, _part='B')
+    for name in ('nmlF', 'nmlB'):
+        t = getattr(g, name, None)
+        if t is None or tuple(t.shape) != (1, 3, h, w):
+            setattr(g, name, torch.empty(1, 3, h, w, device=dev))
+    _broadcast(g.nmlF, 0, group)
+    _broadcast(g.nmlB, 1, group)
+    # (2) the fine hourglass on rank 0, the coarse one on rank 1, the maps to everybody
+    if rank == 0:
+        net.filter_local(fine_image[:, None])
+    if rank == 1:
+        g.filter(coarse_image, _part='hourglass')
+    fh, fw = fine_image.shape[2] // 2, fine_image.shape[3] // 2
+    ff = net.im_feat_list[-1] if rank == 0 else torch.empty(1, int(net.opt.hg_dim), fh, fw, device=dev)
+    fc = g.im_feat_list[-1] if rank == 1 else torch.empty(1, int(g.opt.hg_dim), h // 4, w // 4, device=dev)
+    ff, fc = ff.contiguous(), fc.contiguous()
+    _broadcast(ff, 0, group)
+    _broadcast(fc, 1, group)
+    if rank != 0:
+        net.set_features(ff)
+    if rank != 1:
+        g.set_features(fc)
+    return True
+
+
 # `reconstruction(..., sharded=True)` runs marching cubes over one axis-0 slab per rank from this resolution on (below it
 # the replicated run is a few milliseconds and cheaper than the three exchanges of the slab form)
 SLAB_MC_MIN_RESOLUTION = 1024

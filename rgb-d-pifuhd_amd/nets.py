@@ -276,10 +276,12 @@ class PIFuNetwNML(BasePIFuNet):
         return self
 
     # -- filter ------------------------------------------------------------------------------------
-    def filter(self, images, _defer=False):
+    def filter(self, images, _defer=False, _part=None):
         """`PIFuNetwNML.filter` (`PIFuNetwNML.py:73-97`).  `_defer=True` (used by `reconstruction._Subject`, which calls
         `filter_local` next): return while the hourglass is still running on a stream of the library, so that the fine
-        level runs beside it; `im_feat_list` must then not be read before `filter_local` / a query has been issued."""
+        level runs beside it; `im_feat_list` must then not be read before `filter_local` / a query has been issued.
+        `_part` (`dist.filter_sharded`: the call dealt out over ranks): 'F' / 'B' = that normal net alone (fills
+        `self.nmlF` / `self.nmlB`), 'hourglass' = the HGFilter on the normal maps `self.nmlF` / `self.nmlB` hold."""
         self._sync_weights()
         images = images.to(self.device, torch.float32).contiguous()
         if images.dim() != 4 or images.shape[0] != 1:
@@ -295,17 +297,34 @@ class PIFuNetwNML(BasePIFuNet):
                 raise NotImplementedError("coarse level with hg_down='no_down'")
             raise NameError('unknown downsampling type')                       # Filter.py:197
         use_f, use_b = self.netF is not None, self.netB is not None
-        self.nmlF = torch.empty(1, 3, h, w, device=self.device) if use_f else None
-        self.nmlB = torch.empty(1, 3, h, w, device=self.device) if use_b else None
+        flags = (_lib.ENC_ALL_STACKS if self.training else 0) | (_lib.ENC_DEFER_JOIN if _defer else 0)
+        run_f, run_b = use_f, use_b
+        if _part in ('F', 'B'):
+            run_f, run_b = use_f and _part == 'F', use_b and _part == 'B'
+            flags |= _lib.ENC_NORMALS_ONLY
+        elif _part == 'hourglass':
+            flags |= _lib.ENC_NORMALS_GIVEN
+        elif _part is not None:
+            raise ValueError("_part must be None, 'F', 'B' or 'hourglass'")
+
+        def normal_map(old, wanted, fresh):
+            if not wanted:
+                return None
+            if fresh or old is None or tuple(old.shape) != (1, 3, h, w):
+                return torch.empty(1, 3, h, w, device=self.device)
+            return old                                   # a part of a dealt-out call: the other parts' maps stay
+        self.nmlF = normal_map(getattr(self, 'nmlF', None), use_f, _part is None or _part == 'F')
+        self.nmlB = normal_map(getattr(self, 'nmlB', None), use_b, _part is None or _part == 'B')
         # train mode (train_full_pifu): BatchNorm2d of the HGFilter on batch statistics and EVERY stack's output kept
         # (PIFuNetwNML.py:94-97); eval mode: running statistics, last stack only
         stacks = int(o.num_stack) if self.training else 1
-        feat = torch.empty(stacks, o.hg_dim, h // 4, w // 4, device=self.device)
+        feat = torch.empty(stacks, o.hg_dim, h // 4, w // 4, device=self.device) if _part in (None, 'hourglass') else None
         _lib.call('pifu_filter_coarse', self._ctx.h, _ptr(images), cimg, h, w, int(o.num_stack), int(o.hg_depth),
-                  int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1, int(use_f), int(use_b), _ptr(self.nmlF),
-                  _ptr(self.nmlB), _ptr(feat), (_lib.ENC_ALL_STACKS if self.training else 0) | (_lib.ENC_DEFER_JOIN if _defer else 0),
-                  _stream_ptr(self.device))
-        self.im_feat_list = [feat[k:k + 1] for k in range(stacks)]
+                  int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1,
+                  int(run_f if _part in ('F', 'B') else use_f), int(run_b if _part in ('F', 'B') else use_b),
+                  _ptr(self.nmlF), _ptr(self.nmlB), _ptr(feat), flags, _stream_ptr(self.device))
+        if feat is not None:
+            self.im_feat_list = [feat[k:k + 1] for k in range(stacks)]
         self.normx = None                   # never read on the reconstruction path
 
     def _set_features(self, feat):

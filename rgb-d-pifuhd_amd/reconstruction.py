@@ -137,7 +137,7 @@ class _Subject:
     """One subject on the device after both encoders ran: what every `gen_mesh*` variant of the reference starts with
     (`reconstruction.py:29-45` and its two copies at `:81-97`, `:131-147`)."""
 
-    def __init__(self, net, data):
+    def __init__(self, net, data, sharded=False):
         dev = net.device
         self.calib = data['calib'].to(device=dev)
         # the same matrix on the host, for this package's own calls: they only need its 16 numbers there, and fetching them
@@ -147,9 +147,15 @@ class _Subject:
         # same two calls as the reference, arranged so that independent work overlaps: the coarse call returns while its
         # hourglass still runs (the fine level does not read it), and the 1024 px image crosses PCIe on a copy stream while
         # the normal nets compute
-        net.filter_global(coarse, _defer=True)
-        self.image_fine = _upload_beside(data['img'], dev)
-        net.filter_local(self.image_fine[:, None])
+        if sharded:
+            # one subject over several ranks: the encoders themselves are dealt out (`dist.filter_sharded`)
+            from . import dist as pdist
+            self.image_fine = _upload_beside(data['img'], dev)
+            pdist.filter_sharded(net, coarse, self.image_fine)
+        else:
+            net.filter_global(coarse, _defer=True)
+            self.image_fine = _upload_beside(data['img'], dev)
+            net.filter_local(self.image_fine[:, None])
         # the strip saved beside the mesh: input | front normal | back normal, as far as the coarse net predicts them; of an
         # RGB-D input (6 channels, SURVEY C-7) the colour half is shown
         tiles = [coarse[:, :3]] + [t for t in (net.netG.nmlF, net.netG.nmlB) if t is not None]
@@ -191,7 +197,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
             torch.cuda.current_stream(dev).synchronize()
         return time.perf_counter()
     t0 = mark()
-    subj = _Subject(net, data)
+    subj = _Subject(net, data, sharded=exchange)
     calib_tensor = subj.calib_host
     t1 = mark()
     png_thread = _save_debug_png(save_path[:-4] + '.png', subj.strip, background=True) if rank == 0 else None

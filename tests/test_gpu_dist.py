@@ -58,8 +58,12 @@ def _worker(rank, ws, port, outdir):
     from pifuhd_amd import dist as pdist
     pdist.SLAB_MC_MIN_RESOLUTION = 64
     verts2, faces2, color2 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, result_on='all')
+    # the encoders of the sharded call were dealt out over the two ranks (dist.filter_sharded: netF + fine hourglass on rank 0,
+    # netB + coarse hourglass on rank 1, maps broadcast): what every rank holds afterwards
+    g = netMR.netG
     np.savez(os.path.join(outdir, f'out_r{rank}.npz'), verts=verts, faces=faces, color=color, verts2=verts2, faces2=faces2,
-             color2=color2)
+             color2=color2, nmlF=g.nmlF.cpu().numpy(), nmlB=g.nmlB.cpu().numpy(), feat_coarse=g.im_feat_list[-1].cpu().numpy(),
+             feat_fine=netMR.im_feat_list[-1].cpu().numpy(), filter_collectives=np.array(timings['collectives']))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,8 +84,13 @@ def test_gen_mesh_sharded_world2_matches_single_process(tmp_path):
     netMR, data = _build()
     path = str(tmp_path / 'single.obj')
     verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path)
+    g = netMR.netG
     for r in range(2):
         got = np.load(tmp_path / f'out_r{r}.npz')
+        # the dealt-out encoders leave bit-identical maps on every rank (and 4 broadcasts among the call's collectives)
+        for key, t in (('nmlF', g.nmlF), ('nmlB', g.nmlB), ('feat_coarse', g.im_feat_list[-1]), ('feat_fine', netMR.im_feat_list[-1])):
+            assert np.array_equal(got[key], t.cpu().numpy()), (r, key)
+        assert int(got['filter_collectives']) >= 4 + 2
         assert np.array_equal(got['verts'], verts) and np.array_equal(got['faces'], faces)
         assert np.array_equal(got['color'], color)
         assert np.array_equal(got['verts2'], verts) and np.array_equal(got['faces2'], faces)
