@@ -46,7 +46,7 @@ def read_prof(_lib, h, which, reset=1):
 
 
 def reset_prof(_lib, h):
-    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC, _lib.PROF_ENC):
+    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC, _lib.PROF_ENC, _lib.PROF_MC_NODES, _lib.PROF_WALK):
         _lib.call('pifu_profile_read', h, which, None, None, None, 1)
 
 
@@ -409,6 +409,7 @@ def main():
     _lib.call('pifu_profile_enable', h, 0)
     g_ms, g_n, g_fl = read_prof(_lib, h, _lib.PROF_GEMM)
     gemm_ms, gemm_n, gemm_flops = C.c_double(g_ms), C.c_int64(g_n), C.c_double(g_fl)
+    wk_ms, wk_n, wk_bytes = read_prof(_lib, h, _lib.PROF_WALK)
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if grouped:
@@ -473,6 +474,19 @@ def main():
     # ---- the canonical per-point evaluation (no column sharing, no depth walk: every one of the 2 916 098 FLOP of a query
     # is executed, and the per-point sampler k_sample runs on every point): reported beside the headline, never as `value`
     secondary = []
+    if wk_n > 0 and wk_ms > 0:
+        # the second kernel of the headline step (5 % of it; 8 % of a 512^3 gen_mesh): the depth walk of coarse layer 1
+        ach = wk_bytes / (wk_ms * 1e-3) / 1e9
+        secondary.append({
+            'kernel': 'k_walk<16, 2> (depth walk: coarse layer 1 of the headline step, replaces a 1024 x 512 GEMM per point)',
+            'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+            'launches': wk_n, 'avg_launch_ms': round(wk_ms / wk_n, 4), 'alg_bytes_per_launch': round(wk_bytes / wk_n),
+            'alg_bytes_definition': 'rows x 512 fp32 outputs written + rows depth features read',
+            'frac_of_achievable_write_rate_6300': round(ach / 6300.0, 4),
+            'traffic': (prof_json.get('detail', {}).get('k_walk') or {}).get('hbm_bytes_per_launch'),
+            'traffic_source': traffic_src,
+            'note': 'not at the HBM rate: ~1 000 sign flips per 256-row column segment with the name-seeded weights, each a rank-1 '
+                    'update of (P, R) in double per output - the kernel is bound by fp64 FMA issue first, by the y1 writes second'})
     if world == 1 and not args.no_canonical and not args.no_column_sharing:
         try:
             cflags = flags | _lib.Q_NO_COLUMN_SHARING
@@ -752,6 +766,8 @@ def main():
                 _lib.call('pifu_profile_enable', h, 0)
                 mc_ms, mc_n, mc_bytes = read_prof(_lib, h, _lib.PROF_MC)
                 mc_ms, mc_bytes = mc_ms / len(runs), mc_bytes / len(runs)
+                nd_ms, nd_n, nd_bytes = read_prof(_lib, h, _lib.PROF_MC_NODES)
+                nd_ms, nd_bytes = nd_ms / max(nd_n, 1), nd_bytes / max(nd_n, 1)
                 gm_ms, gm_n, gm_fl = read_prof(_lib, h, _lib.PROF_GEMM)          # the MLP GEMM launches of the timed runs
                 _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)               # the encoders' convolutions (counted, not timed)
                 gm_ms, gm_n, gm_fl, en_n, en_fl = gm_ms / len(runs), gm_n // len(runs), gm_fl / len(runs), en_n // len(runs), en_fl / len(runs)
@@ -808,7 +824,18 @@ def main():
                         # doubled (gfx950) + WRITE_SIZE, summed over the marching-cubes kernels of one call
                         'traffic': prof_json.get('mc_hbm_bytes_per_call_512_body'),
                         'traffic_source': 'profiles/traffic.json (tools/mc_prof.sh PMC passes on a 512^3 analytic body, an earlier run)'
-                        if prof_json.get('mc_hbm_bytes_per_call_512_body') else None})
+                        if prof_json.get('mc_hbm_bytes_per_call_512_body') else None,
+                        'note': 'only the node pass below streams the volume; the classification works on the cells of the bricks that '
+                                'hold surface (4.2 M surface cells on this subject) and is latency-bound (k_mc_count), so the HBM '
+                                'fraction of the whole is not a statement about bandwidth use'})
+                if nd_ms > 0:
+                    ach = nd_bytes / (nd_ms * 1e-3) / 1e9
+                    secondary.append({
+                        'kernel': 'k_mc_nodebricks (marching cubes, node pass: the one kernel that reads the whole float64 SDF)',
+                        'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+                        'avg_launch_ms': round(nd_ms, 4), 'launches': nd_n, 'alg_bytes_per_launch': round(nd_bytes),
+                        'alg_bytes_definition': 'R^3 x 8 B read once (value range + which 9^3-node bricks can hold surface)',
+                        'traffic': None})
                 # parity of the mesh the timed run produced: the same grid once more (not timed), marching cubes on a 128^3
                 # crop around the surface on the GPU and on the serial oracle - vertices and faces must agree bit for bit
                 r = mesh_util.reconstruction(netMR, dev, calib, args.genmesh_res, None, None, 0.5, use_octree=True,

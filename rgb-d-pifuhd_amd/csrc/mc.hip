@@ -646,8 +646,15 @@ int mc_count_impl(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, 
         v.brick = nullptr; v.gflag = nullptr;
         // two x per thread when the rows (and with them every 16-byte load) are aligned
         const bool vec = n2 % 2 == 0 && ((uintptr_t)volume % 16) == 0;
+        // timed on its own as well (PIFU_PROF_MC_NODES): the one pass of marching cubes that streams the volume, i.e. the part
+        // the HBM roofline prices; everything after it works on the few per cent of the cells that hold surface
+        hipEvent_t nodes_stop;
+        rc = pifu_prof_begin(ctx, PIFU_PROF_MC_NODES, st, &nodes_stop);
+        if (rc) return rc;
         if (vec) hipLaunchKernelGGL(k_mc_nodebricks<2>, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
         else hipLaunchKernelGGL(k_mc_nodebricks<1>, dim3((unsigned)npencils), dim3(256), 0, st, v, a.nb1, a.nb2, a.nbflags, a.mm + 2);
+        rc = pifu_prof_end(ctx, PIFU_PROF_MC_NODES, nodes_stop, (double)n0 * n1 * n2 * (dtype ? 8.0 : 4.0), st);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_mc_minmax_final, dim3(1), dim3(256), 0, st, (const float *)(a.mm + 2), npencils, a.mm);
         hipLaunchKernelGGL(k_mc_brick_combine, dim3((unsigned)((a.nbricks + 255) / 256)), dim3(256), 0, st, v, a.nb0, a.nb1, a.nb2,
                            (const uint16_t *)a.nbflags, a.brick);

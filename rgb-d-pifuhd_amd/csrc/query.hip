@@ -1801,6 +1801,11 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 wa.flip_key = w.flip_key; wa.flip_d = w.flip_d; wa.nflips = w.nflips;
                 wa.zf = pl.zf; wa.seg_row0 = w.seg_row0; wa.nseg = nseg; wa.g = g; wa.C0 = C0; wa.N1 = N1;
                 wa.Y = b.out[i]; wa.ldy = l.cout_pad; wa.partial_seg = stats ? w.partial_seg : nullptr;
+                // timed for bench.py (PIFU_PROF_WALK): work = the bytes it must move - y1 written (rows x N1 floats) + the depth
+                // features read; the weight rows of the flips are L2 traffic
+                hipEvent_t walk_stop;
+                rc = pifu_prof_begin(ctx, PIFU_PROF_WALK, st, &walk_stop);
+                if (rc) return rc;
 #ifdef PIFU_LAB     // tools/walk_ab.sh
                 const int wv = ctx->walk_variant;
                 if (wv == 1) hipLaunchKernelGGL(k_walk_v1<1>, dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
@@ -1813,6 +1818,8 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
 #endif
                 if (N1 % 512 == 0) hipLaunchKernelGGL((k_walk<16, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
                 else hipLaunchKernelGGL((k_walk<16, 1>), dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
+                rc = pifu_prof_end(ctx, PIFU_PROF_WALK, walk_stop, (double)rows * ((double)N1 * 4.0 + 4.0), st);
+                if (rc) return rc;
                 if (stats) {
                     const int groups = m.norm == PIFU_NORM_GROUP ? 32 : l.cout;
                     hipLaunchKernelGGL(k_norm_finalize, dim3(g.nchunks * groups), dim3(256), 0, st, (const float2 *)w.partial_seg,
