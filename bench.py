@@ -46,7 +46,7 @@ def read_prof(_lib, h, which, reset=1):
 
 
 def reset_prof(_lib, h):
-    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC, _lib.PROF_ENC, _lib.PROF_MC_NODES, _lib.PROF_WALK):
+    for which in (_lib.PROF_GEMM, _lib.PROF_SAMPLER, _lib.PROF_MC, _lib.PROF_ENC, _lib.PROF_MC_NODES, _lib.PROF_WALK, _lib.PROF_ENC_CANONICAL):
         _lib.call('pifu_profile_read', h, which, None, None, None, 1)
 
 
@@ -684,7 +684,9 @@ def main():
                 passes.append(time.perf_counter() - e0)
             _lib.call('pifu_profile_enable', h, 0)
             _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)
+            _, _, en_canon = read_prof(_lib, h, _lib.PROF_ENC_CANONICAL)
             en_fl /= len(passes)
+            en_canon /= len(passes)
             p_med = sorted(passes)[len(passes) // 2]
             secondary.append({
                 'kernel': 'encoders: k_conv_dma<64|32> (+ k_prep_act, statistics, split-K reduce) of filter_global + filter_local, one image',
@@ -692,8 +694,13 @@ def main():
                 'frac': round(en_fl / p_med / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4), 'pass_ms': round(p_med * 1e3, 3),
                 'passes_ms': [round(p * 1e3, 3) for p in passes], 'conv_launches_per_pass': en_n // len(passes),
                 'alg_tflop_per_pass': round(en_fl / 1e12, 4),
+                # the 36 convolutions of the normal nets' ResnetBlock trunks (1024 -> 1024, 3 x 3, 32 x 32) run as Winograd
+                # F(2x2, 3x3): `achieved` / `frac` price what is EXECUTED; as direct convolutions the same pass would be
+                'direct_convolution_tflop_per_pass': round(en_canon / 1e12, 4),
+                'direct_convolution_equivalent_frac': round(en_canon / p_med / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                 'definition': 'host image -> both feature maps resident (upload of the 1024 px image included), wall clock of a '
-                              'steady-state pass; FLOPs = 2 * output pixels * Cout * Cin * taps summed over the convolutions (counted by the library)'})
+                              'steady-state pass; FLOPs = 2 * output pixels * Cout * Cin * taps summed over the convolutions (2 * 16 * '
+                              'tiles * Cout * Cin for the Winograd ones), counted by the library'})
             cold['steady_encoder_pass_s'] = round(p_med, 4)
             log(f"encoders: {p_med * 1e3:.2f} ms per image, {en_fl / p_med / 1e12:.1f} TFLOP/s")
         except Exception as e:

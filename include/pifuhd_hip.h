@@ -340,9 +340,12 @@ int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, 
  * ALGORITHMIC FLOPs, 2 * output pixels * Cout * Cin * taps; they run on up to three concurrent streams of the library, so they are
  * counted, not timed: ms = 0 - time the pass as a whole), PIFU_PROF_MC_NODES = the node pass of marching cubes alone
  * (k_mc_nodebricks: the one kernel that streams the whole volume; work = n0 * n1 * n2 * sizeof(value)), PIFU_PROF_WALK = the
- * depth walk of coarse layer 1 on lattice sources (k_walk; work = the bytes it must move: rows x (N1 + 1) floats).
+ * depth walk of coarse layer 1 on lattice sources (k_walk; work = the bytes it must move: rows x (N1 + 1) floats),
+ * PIFU_PROF_ENC_CANONICAL = the same launches as PIFU_PROF_ENC priced as DIRECT convolutions (PIFU_PROF_ENC counts what is
+ * executed: the 3 x 3 convolutions of the normal nets' ResnetBlock trunk run as Winograd F(2x2, 3x3), 2.25 x fewer multiplies).
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms), launches, work. */
-enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2, PIFU_PROF_ENC = 3, PIFU_PROF_MC_NODES = 4, PIFU_PROF_WALK = 5 };
+enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2, PIFU_PROF_ENC = 3, PIFU_PROF_MC_NODES = 4, PIFU_PROF_WALK = 5,
+       PIFU_PROF_ENC_CANONICAL = 6 };
 int pifu_profile_enable(pifu_ctx *ctx, int on);
 int pifu_profile_read(pifu_ctx *ctx, int which, double *ms, int64_t *launches, double *work, int reset);
 

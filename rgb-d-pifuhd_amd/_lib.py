@@ -15,7 +15,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
-PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC, PROF_MC_NODES, PROF_WALK = 0, 1, 2, 3, 4, 5
+PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC, PROF_MC_NODES, PROF_WALK, PROF_ENC_CANONICAL = 0, 1, 2, 3, 4, 5, 6
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
 ENC_ALL_STACKS, ENC_DEFER_JOIN, ENC_NORMALS_ONLY, ENC_NORMALS_GIVEN = 1, 2, 4, 8
 PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables

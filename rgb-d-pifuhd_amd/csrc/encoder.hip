@@ -136,6 +136,10 @@ struct ConvDmaArgs {
     // then needs no pass of its own over the tensor
     double *stat;               // or null
     int stat_tile0;             // first partial row of this launch (the four parity classes of a transposed conv share one set)
+    // batched GEMM (the 16 positions of a Winograd convolution as ONE launch): row tiles [g * wg_tiles, (g + 1) * wg_tiles)
+    // multiply the weight matrix W + g * wg_stride (floats); wg_tiles == 0: one weight matrix for all rows
+    int wg_tiles;
+    size_t wg_stride;
 };
 
 template <int TN>
@@ -158,7 +162,8 @@ __device__ __forceinline__ void conv_dma_tile(const ConvDmaArgs &a, const int bl
     const int step_lo = split * a.steps_per_split;
     const int step_hi = min(a.ldw / BK, step_lo + a.steps_per_split);
 
-    const unsigned long long pa = (unsigned long long)a.P, wa = (unsigned long long)(a.W + (size_t)col0 * a.ldw);
+    const unsigned long long pa = (unsigned long long)a.P,
+                             wa = (unsigned long long)(a.W + (size_t)col0 * a.ldw + (a.wg_tiles ? (size_t)(tile_m / a.wg_tiles) * a.wg_stride : 0));
     const u32x4 rP = {(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, a.p_bytes, 0x00020000u};
     const u32x4 rWt = {(unsigned)wa, (unsigned)(wa >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     // DMA lane mapping: lane (r8 = lane >> 3, p = lane & 7) of wave w fills, in pass q, chunk position p of tile row
@@ -661,6 +666,177 @@ __global__ void k_nhwc_to_nchw(const float *src, int ld, int C, int HW, float *d
     }
 }
 
+// ---- Winograd F(2x2, 3x3) for the ResnetBlock trunk of the normal nets (networks.py:162-207) ------------------------------
+// 36 of a pass's convolutions are 1024 -> 1024, 3 x 3, stride 1, reflection pad 1 on a 32 x 32 map: 696 of the encoders' 2 002
+// GFLOP.  Y = A^T [(G g G^T) . (B^T d B)] A turns each into 16 GEMMs [256 tiles x 1024] x [1024 x 1024] - 2.25 x fewer
+// multiplies, exact in real arithmetic, fp32 rounding within 2 x of the direct sum's (6e-7 relative on this shape) - and what
+// sits BETWEEN two of them is separable per channel: output transform + bias, InstanceNorm statistics over the 1 024 pixels,
+// normalise, ReLU or residual add, reflection pad and the next convolution's input transform.  k_wino_bridge does all of it in
+// one launch, a block per 16 channels with the whole 32 x 32 plane of those channels in LDS: the direct path's split-K reduce,
+// statistics, finalize and prepared-input kernels (and their launches) between two trunk convolutions are gone.
+constexpr int WCG = 16;            // channels per block of the bridge
+constexpr int WPX = WCG + 4;       // floats per pixel in LDS (padded: neighbouring tiles land in different banks)
+
+// U[p][o][c] = (G g G^T)[p / 4][p % 4] of the 3 x 3 kernel g = w[o][c]
+__global__ void k_wino_weight(const float *w, int co, int ci, float *U)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)co * ci) return;
+    const float *g = w + idx * 9;
+    float Gg[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Gg[0][k] = g[k];
+        Gg[1][k] = 0.5f * (g[k] + g[3 + k] + g[6 + k]);
+        Gg[2][k] = 0.5f * (g[k] - g[3 + k] + g[6 + k]);
+        Gg[3][k] = g[6 + k];
+    }
+    const size_t plane = (size_t)co * ci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        U[(size_t)(i * 4 + 0) * plane + idx] = Gg[i][0];
+        U[(size_t)(i * 4 + 1) * plane + idx] = 0.5f * (Gg[i][0] + Gg[i][1] + Gg[i][2]);
+        U[(size_t)(i * 4 + 2) * plane + idx] = 0.5f * (Gg[i][0] - Gg[i][1] + Gg[i][2]);
+        U[(size_t)(i * 4 + 3) * plane + idx] = Gg[i][2];
+    }
+}
+
+struct WinoArgs {
+    const float *M;        // [16][T][C] products of the convolution just finished (modes 1, 2)
+    float *V;              // [16][T][C] transformed input of the next convolution (null: none follows)
+    float *R;              // [H * W][C] the residual stream (mode 0: read; mode 2: read, updated in place)
+    const float *bias;     // [C] of the convolution just finished (modes 1, 2)
+    int H, W, C, T;        // T = (H / 2) * (W / 2) tiles
+    int mode;              // 0: V <- R;  1: V <- relu(IN(conv + bias));  2: R += IN(conv + bias), V <- R
+    float eps;
+};
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(256) void k_wino_bridge(const WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wino_lds[];
+    float *h = wino_lds;                                           // [H * W][WPX]
+    double *red = reinterpret_cast<double *>(wino_lds + (size_t)a.H * a.W * WPX);     // [4 waves][WCG][2]
+    float *aff = reinterpret_cast<float *>(red + 4 * WCG * 2);     // [2][WCG] scale | shift
+    const int tid = threadIdx.x, c4 = tid & 3, ts = tid >> 2;      // four lanes cover a tile's 16 channels (64 contiguous bytes)
+    const int c0 = blockIdx.x * WCG + 4 * c4;
+    const int TW = a.W / 2;
+    const size_t plane = (size_t)a.T * a.C;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (a.mode == 0) {
+        for (int px = ts; px < a.H * a.W; px += 64)
+            *reinterpret_cast<float4 *>(h + px * WPX + 4 * c4) = *reinterpret_cast<const float4 *>(a.R + (size_t)px * a.C + c0);
+    } else {
+        // output transform A^T m A of every tile (+ bias) into the plane, statistics on the way
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + c0);
+        for (int t = ts; t < a.T; t += 64) {
+            float4 m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = *reinterpret_cast<const float4 *>(a.M + p * plane + (size_t)t * a.C + c0);
+            float4 t0[4], t1[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                t0[l] = f4_add(f4_add(m[l], m[4 + l]), m[8 + l]);
+                t1[l] = f4_sub(f4_sub(m[4 + l], m[8 + l]), m[12 + l]);
+            }
+            float4 y[4];
+            y[0] = f4_add(f4_add(f4_add(t0[0], t0[1]), t0[2]), b);
+            y[1] = f4_add(f4_sub(f4_sub(t0[1], t0[2]), t0[3]), b);
+            y[2] = f4_add(f4_add(f4_add(t1[0], t1[1]), t1[2]), b);
+            y[3] = f4_add(f4_sub(f4_sub(t1[1], t1[2]), t1[3]), b);
+            const int ty = t / TW, tx = t - ty * TW;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = (2 * ty + (k >> 1)) * a.W + 2 * tx + (k & 1);
+                *reinterpret_cast<float4 *>(h + px * WPX + 4 * c4) = y[k];
+                ssum = f4_add(ssum, y[k]);
+                ssq.x = fmaf(y[k].x, y[k].x, ssq.x); ssq.y = fmaf(y[k].y, y[k].y, ssq.y);
+                ssq.z = fmaf(y[k].z, y[k].z, ssq.z); ssq.w = fmaf(y[k].w, y[k].w, ssq.w);
+            }
+        }
+        // InstanceNorm2d(affine=False) statistics of this block's 16 channels over the whole plane: fixed-order double sums
+        double sd[4] = {(double)ssum.x, (double)ssum.y, (double)ssum.z, (double)ssum.w};
+        double qd[4] = {(double)ssq.x, (double)ssq.y, (double)ssq.z, (double)ssq.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) { sd[k] += __shfl_xor(sd[k], o); qd[k] += __shfl_xor(qd[k], o); }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                red[((wave * WCG) + 4 * lane + k) * 2] = sd[k];
+                red[((wave * WCG) + 4 * lane + k) * 2 + 1] = qd[k];
+            }
+        }
+        __syncthreads();
+        if (tid < WCG) {
+            double s1 = 0.0, q1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[((w * WCG) + tid) * 2]; q1 += red[((w * WCG) + tid) * 2 + 1]; }
+            const double cnt = (double)a.H * a.W, mean = s1 / cnt;
+            double var = q1 / cnt - mean * mean;
+            var = var > 0 ? var : 0;
+            const double rstd = 1.0 / sqrt(var + (double)a.eps);
+            aff[tid] = (float)rstd;
+            aff[WCG + tid] = (float)(-mean * rstd);
+        }
+        __syncthreads();
+        // normalise in place: ReLU (the second convolution's input) or the residual add (the block's output)
+        const float4 sc = *reinterpret_cast<const float4 *>(aff + 4 * c4), sh = *reinterpret_cast<const float4 *>(aff + WCG + 4 * c4);
+        for (int px = ts; px < a.H * a.W; px += 64) {
+            float4 v = *reinterpret_cast<const float4 *>(h + px * WPX + 4 * c4);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            if (a.mode == 1) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else {
+                float *rp = a.R + (size_t)px * a.C + c0;
+                const float4 r = *reinterpret_cast<const float4 *>(rp);
+                v = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);      // x + conv_block(x): ResnetBlock.forward
+                *reinterpret_cast<float4 *>(rp) = v;
+            }
+            *reinterpret_cast<float4 *>(h + px * WPX + 4 * c4) = v;
+        }
+    }
+    __syncthreads();
+    if (!a.V) return;
+    // input transform B^T d B of every 4 x 4 patch (stride 2) of the reflection-padded plane
+    for (int t = ts; t < a.T; t += 64) {
+        const int ty = t / TW, tx = t - ty * TW;
+        float4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int yy = 2 * ty - 1 + i;
+            yy = yy < 0 ? -yy : (yy >= a.H ? 2 * a.H - 2 - yy : yy);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int xx = 2 * tx - 1 + j;
+                xx = xx < 0 ? -xx : (xx >= a.W ? 2 * a.W - 2 - xx : xx);
+                d[i][j] = *reinterpret_cast<const float4 *>(h + (yy * a.W + xx) * WPX + 4 * c4);
+            }
+        }
+        float4 u[4][4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            u[0][l] = f4_sub(d[0][l], d[2][l]);
+            u[1][l] = f4_add(d[1][l], d[2][l]);
+            u[2][l] = f4_sub(d[2][l], d[1][l]);
+            u[3][l] = f4_sub(d[1][l], d[3][l]);
+        }
+        float *vp = a.V + (size_t)t * a.C + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(vp + (size_t)(i * 4 + 0) * plane) = f4_sub(u[i][0], u[i][2]);
+            *reinterpret_cast<float4 *>(vp + (size_t)(i * 4 + 1) * plane) = f4_add(u[i][1], u[i][2]);
+            *reinterpret_cast<float4 *>(vp + (size_t)(i * 4 + 2) * plane) = f4_sub(u[i][2], u[i][1]);
+            *reinterpret_cast<float4 *>(vp + (size_t)(i * 4 + 3) * plane) = f4_sub(u[i][1], u[i][3]);
+        }
+    }
+}
+
 // ---- weight packing on the device ---------------------------------------------------------------------------------
 // dst [cout_pad][ldw] <- a Conv2d weight [cout][d1][kh][kw] (or ConvTranspose2d [ci][cout][kh][kw]): per K run (span) the
 // taps (ky, kx[i]) of `nx` consecutive pixels, C channels each (zero beyond the weight's `ci` and where a run is padded to
@@ -750,11 +926,14 @@ struct EncState {
 
 // books one convolution's ALGORITHMIC work (2 * output pixels * Cout * Cin * taps; padding of K / Cout not counted) while
 // profiling is on; the launches run on up to three concurrent lanes, so they are counted, not timed (the pass is timed whole)
-inline void book_conv(EncState &S, double flops)
+inline void book_conv(EncState &S, double flops, double canonical = -1.0)
 {
     if (S.ctx && S.ctx->prof_on) {
-        S.ctx->prof[PIFU_PROF_ENC].work += flops;
+        S.ctx->prof[PIFU_PROF_ENC].work += flops;                 // what the launch executes
         S.ctx->prof[PIFU_PROF_ENC].launches += 1;
+        // what the direct convolution would execute (differs for the Winograd trunk of the normal nets: x 2.25)
+        S.ctx->prof[PIFU_PROF_ENC_CANONICAL].work += canonical >= 0.0 ? canonical : flops;
+        S.ctx->prof[PIFU_PROF_ENC_CANONICAL].launches += 1;
     }
 }
 
@@ -1252,6 +1431,60 @@ Tensor hg_filter(EncState &S, const std::string &p, const Tensor &in32, int n_st
     return out;
 }
 
+// ---- the ResnetBlock trunk through Winograd F(2x2, 3x3) (kernels above) --------------------------------------------------
+bool wino_ok(const Tensor &r, int c)
+{
+    if (r.H % 2 || r.W % 2 || r.ld != c || c % 64 || c % WCG) return false;
+    const int T = (r.H / 2) * (r.W / 2);
+    // whole 128-row GEMM tiles per Winograd position, and the plane of 16 channels in (half of) a CU's LDS
+    return T % BM == 0 && (size_t)r.H * r.W * WPX * 4 + 2048 <= (size_t)96 * 1024;
+}
+
+const float *wino_weight(EncState &S, const std::string &wname, int c)
+{
+    const std::string key = wname + "#wino";
+    if (S.dev.count(key)) return S.dev[key];
+    HostParam &w = param(S, wname);
+    if (w.shape.size() != 4 || w.shape[0] != c || w.shape[1] != c || w.shape[2] != 3 || w.shape[3] != 3)
+        throw Fail{wname + ": expected a [C][C][3][3] weight"};
+    const float *src = raw_on_device(S, wname, w);
+    float *d = nullptr;
+    if (hipMalloc(&d, (size_t)16 * c * c * sizeof(float)) != hipSuccess) throw Fail{"hipMalloc failed for " + key};
+    hipLaunchKernelGGL(k_wino_weight, dim3(nblk((size_t)c * c, 256)), dim3(256), 0, S.cur->st, src, c, c, d);
+    S.dev[key] = d;
+    return d;
+}
+
+// M[16][T][c] = V[16][T][c] x U[16][c][c]^T: the 16 positions as one launch of the convolution kernel (a 1 x 1 "convolution"
+// over 16 T rows whose weight matrix changes every T / 128 row tiles)
+void wino_gemm(EncState &S, const float *V, const float *U, float *M, int T, int c, int H, int W)
+{
+    ConvDmaArgs a{};
+    const int rows = 16 * T;
+    a.P = V; a.p_bytes = (unsigned)((size_t)rows * c * 4);
+    a.Wp = rows; a.C = c; a.RW = rows; a.nrows = rows; a.is = 1;
+    a.nspan = 1; a.span_off[0] = 0; a.span_steps[0] = c / BK;
+    a.W = U; a.ldw = c; a.bias = zeros(S);
+    a.Y = M; a.ldy = c; a.cout = c;
+    a.os = 1; a.oy0 = 0; a.ox0 = 0; a.Wout = rows;
+    a.wg_tiles = T / BM; a.wg_stride = (size_t)c * c;
+    launch_conv_dma(S, a, 64);
+    book_conv(S, 2.0 * 16.0 * T * (double)c * c, 2.0 * H * W * (double)c * c * 9.0);
+}
+
+void wino_bridge(EncState &S, const WinoArgs &wa)
+{
+    const size_t lds = (size_t)wa.H * wa.W * WPX * 4 + 4 * WCG * 2 * sizeof(double) + 2 * WCG * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino_bridge), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess)
+            throw Fail{"k_wino_bridge: cannot reserve its LDS"};
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_wino_bridge, dim3(wa.C / WCG), dim3(256), lds, S.cur->st, wa);
+}
+
 // GlobalGenerator (networks.py:131-207) with InstanceNorm(affine=False); returns NCHW [3][H][W] in `dst`
 void global_generator(EncState &S, const std::string &p, const Tensor &in32, float *dst_nchw)
 {
@@ -1272,6 +1505,26 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, act.scale,
                        act.shift, 0.f, r.p, r.ld, c, r.pixels());
     const ConvGeom gr{3, 1, 1, true};
+    if (wino_ok(r, c)) {
+        // the trunk through Winograd: `r` is the residual stream (updated in place by every block), V / M the transformed
+        // input and the products of the convolution in flight (one buffer each: the launches are stream-ordered)
+        const int T = (r.H / 2) * (r.W / 2);
+        float *V = arena_take(S, (size_t)16 * T * c), *M = arena_take(S, (size_t)16 * T * c);
+        WinoArgs wa{};
+        wa.M = M; wa.V = V; wa.R = r.p; wa.H = r.H; wa.W = r.W; wa.C = c; wa.T = T; wa.eps = 1e-5f;
+        wa.mode = 0; wa.bias = nullptr;
+        wino_bridge(S, wa);
+        for (int b = 0; b < 9; ++b) {
+            const std::string q = p + ".model." + std::to_string(idx) + ".conv_block";
+            wino_gemm(S, V, wino_weight(S, q + ".1.weight", c), M, T, c, r.H, r.W);
+            wa.mode = 1; wa.bias = dev_upload(S, q + ".1.bias", param(S, q + ".1.bias").data); wa.V = V;
+            wino_bridge(S, wa);                                   // relu(IN(conv1)) -> conv2's input
+            wino_gemm(S, V, wino_weight(S, q + ".5.weight", c), M, T, c, r.H, r.W);
+            wa.mode = 2; wa.bias = dev_upload(S, q + ".5.bias", param(S, q + ".5.bias").data); wa.V = b < 8 ? V : nullptr;
+            wino_bridge(S, wa);                                   // r += IN(conv2) -> the next block's input
+            idx += 1;
+        }
+    } else
     for (int b = 0; b < 9; ++b) {
         const std::string q = p + ".model." + std::to_string(idx) + ".conv_block";
         Tensor h1 = new_tensor(S, r.H, r.W, c), h2 = new_tensor(S, r.H, r.W, c), o = new_tensor(S, r.H, r.W, c);

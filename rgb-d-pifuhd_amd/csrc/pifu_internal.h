@@ -34,7 +34,7 @@ constexpr int PIFU_BN = 128;   // output channels per block tile
 constexpr int PIFU_BK = 32;    // K step; every K segment is padded to a multiple of it
 constexpr int PIFU_MAX_LAYERS = 8;
 constexpr int PIFU_MAX_WIDTH = 8192;  // widest MLP layer / input supported
-constexpr int PIFU_PROF_SLOTS = 6;    // PIFU_PROF_GEMM, _SAMPLER, _MC, _ENC, _MC_NODES, _WALK
+constexpr int PIFU_PROF_SLOTS = 7;    // PIFU_PROF_GEMM, _SAMPLER, _MC, _ENC, _MC_NODES, _WALK, _ENC_CANONICAL
 
 static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
