@@ -69,6 +69,9 @@ enum {
     PIFU_ENC_NORMALS_GIVEN = 8,            /* nmlF / nmlB are INPUTS (device NCHW [1][3][H][W], e.g. computed by other ranks):
                                               the normal nets are skipped, the hourglass runs on cat[img, nmlF, nmlB].  The
                                               two halves of PIFuNetwNML.filter for callers that deal them to different GPUs */
+    PIFU_ENC_NO_WINOGRAD = 16,             /* the 3 x 3 convolutions of the normal nets' ResnetBlock trunks as direct convolutions
+                                              instead of Winograd F(2x2, 3x3) (the default where the trunk's map allows it:
+                                              32 x 32, i.e. 512 x 512 images; same result up to fp32 rounding, ~1e-6 relative) */
     PIFU_ENC_DEFER_JOIN = 2                /* return while the coarse hourglass is still running on a stream of the library:
                                               pifu_filter_fine - which reads the normal maps, not the coarse features -
                                               then runs beside it.  The caller's stream is made to wait for the hourglass by

@@ -17,7 +17,7 @@ LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
 PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC, PROF_MC_NODES, PROF_WALK, PROF_ENC_CANONICAL = 0, 1, 2, 3, 4, 5, 6
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
-ENC_ALL_STACKS, ENC_DEFER_JOIN, ENC_NORMALS_ONLY, ENC_NORMALS_GIVEN = 1, 2, 4, 8
+ENC_ALL_STACKS, ENC_DEFER_JOIN, ENC_NORMALS_ONLY, ENC_NORMALS_GIVEN, ENC_NO_WINOGRAD = 1, 2, 4, 8, 16
 PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables
 PIXEL_TABLE_MIN_POINTS = 16384            # the automatic threshold: max(this, H * W of the coarse map) points per call
 ARENA_QUERY, ARENA_MC, ARENA_OCTREE, ARENA_COLUMN, ARENA_PIXEL, ARENA_MISC = 0, 1, 2, 3, 4, 5

@@ -920,6 +920,7 @@ struct EncState {
     bool coarse_pending = false;                 // the deferred coarse hourglass has been issued and not yet joined
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
+    bool direct_trunk = false;                   // PIFU_ENC_NO_WINOGRAD: the ResnetBlock trunks as direct convolutions
     pifu_ctx *ctx = nullptr;                     // owner (pifu_profile_*: algorithmic FLOPs of the convolutions, slot PIFU_PROF_ENC)
     std::string err;
 };
@@ -1505,7 +1506,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, act.scale,
                        act.shift, 0.f, r.p, r.ld, c, r.pixels());
     const ConvGeom gr{3, 1, 1, true};
-    if (wino_ok(r, c)) {
+    if (wino_ok(r, c) && !S.direct_trunk) {
         // the trunk through Winograd: `r` is the residual stream (updated in place by every block), V / M the transformed
         // input and the products of the convolution in flight (one buffer each: the launches are stream-ordered)
         const int T = (r.H / 2) * (r.W / 2);
@@ -1738,6 +1739,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     // maps another rank computed): NORMALS_ONLY stops after the enabled normal nets, NORMALS_GIVEN reads nmlF / nmlB as inputs
     const bool normals_only = (flags & PIFU_ENC_NORMALS_ONLY) != 0, normals_given = (flags & PIFU_ENC_NORMALS_GIVEN) != 0;
     PIFU_REQUIRE(!(normals_only && normals_given), PIFU_ERR_INVALID, "pifu_filter_coarse: NORMALS_ONLY and NORMALS_GIVEN exclude each other");
+    state_of(ctx).direct_trunk = (flags & PIFU_ENC_NO_WINOGRAD) != 0;
     EncState &S = state_of(ctx);
     hipStream_t st = (hipStream_t)stream;
     const size_t px = (size_t)H * W;

@@ -298,6 +298,8 @@ class PIFuNetwNML(BasePIFuNet):
             raise NameError('unknown downsampling type')                       # Filter.py:197
         use_f, use_b = self.netF is not None, self.netB is not None
         flags = (_lib.ENC_ALL_STACKS if self.training else 0) | (_lib.ENC_DEFER_JOIN if _defer else 0)
+        if getattr(self, '_direct_trunk', False):           # A/B hook of the tests: the normal nets' trunks as direct convolutions
+            flags |= _lib.ENC_NO_WINOGRAD
         run_f, run_b = use_f, use_b
         if _part in ('F', 'B'):
             run_f, run_b = use_f and _part == 'F', use_b and _part == 'B'

@@ -263,6 +263,32 @@ def test_full_size_pifuhd_checkpoint_configuration_end_to_end(golden_dir, observ
     assert np.median(cos) > 0.999 and (cos > 0.9).mean() > 0.95
 
 
+def test_winograd_trunk_against_the_direct_convolutions(observed):
+    """The ResnetBlock trunks of the normal nets (`networks.py:162-207`: 18 convolutions 1024 -> 1024, 3 x 3, reflection pad,
+    on the 32 x 32 map of a 512 x 512 image) run as Winograd F(2x2, 3x3) - 16 batched GEMMs + one channel-separable bridge
+    kernel between two of them.  Against the same nets with `PIFU_ENC_NO_WINOGRAD` (direct convolutions, the round-4 path): the
+    normal maps agree to fp32 rounding, are not bit-identical (both paths ran), and the full-size goldens of the reference hold
+    for both (`test_full_size_*`)."""
+    from pifuhd_amd import config, nets, synth
+    oc = config.coarse_opt(); of = config.fine_opt(oc)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.16)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    img = synth.synthetic_inputs(1024, 3, seed=0)['img_512']
+    netG.filter(img)
+    wino = [t.clone() for t in (netG.nmlF, netG.nmlB, netG.im_feat_list[0])]
+    netG._direct_trunk = True
+    netG.filter(img)
+    direct = [t.clone() for t in (netG.nmlF, netG.nmlB, netG.im_feat_list[0])]
+    netG._direct_trunk = False
+    netG.filter(img)
+    again = [netG.nmlF, netG.nmlB, netG.im_feat_list[0]]
+    errs = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(wino, direct)]
+    observed('winograd_vs_direct', nmlF_rel=errs[0], nmlB_rel=errs[1], feat_coarse_rel=errs[2])
+    assert all(not torch.equal(a, b) for a, b in zip(wino[:2], direct[:2]))
+    assert max(errs) < 2e-5, errs
+    assert all(torch.equal(a, b) for a, b in zip(wino, again))          # deterministic, and the switch leaves nothing behind
+
+
 def test_overlapped_encoder_schedule_is_bit_identical():
     """`reconstruction._Subject` issues the two filter calls so that independent work overlaps (netF beside netB inside the
     coarse call, the coarse hourglass - left running by PIFU_ENC_DEFER_JOIN - beside the fine level, the fine image's upload
