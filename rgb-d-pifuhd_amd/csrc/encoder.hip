@@ -921,6 +921,7 @@ struct EncState {
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
     bool direct_trunk = false;                   // PIFU_ENC_NO_WINOGRAD: the ResnetBlock trunks as direct convolutions
+    bool wino_configured = false;                // k_wino_bridge's dynamic LDS size has been set on this context's device
     pifu_ctx *ctx = nullptr;                     // owner (pifu_profile_*: algorithmic FLOPs of the convolutions, slot PIFU_PROF_ENC)
     std::string err;
 };
@@ -1476,12 +1477,11 @@ void wino_gemm(EncState &S, const float *V, const float *U, float *M, int T, int
 void wino_bridge(EncState &S, const WinoArgs &wa)
 {
     const size_t lds = (size_t)wa.H * wa.W * WPX * 4 + 4 * WCG * 2 * sizeof(double) + 2 * WCG * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    if (!S.wino_configured) {          // per context, i.e. per device: the plane of 16 channels needs more than the default 64 KB
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino_bridge), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
             hipSuccess)
             throw Fail{"k_wino_bridge: cannot reserve its LDS"};
-        configured = true;
+        S.wino_configured = true;
     }
     hipLaunchKernelGGL(k_wino_bridge, dim3(wa.C / WCG), dim3(256), lds, S.cur->st, wa);
 }

@@ -188,13 +188,6 @@ def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, th
     return sdf, evaluated
 
 
-def shard_range(n_items: int, world_size: int, rank: int):
-    """Contiguous share [i0, i1) of `n_items` for `rank`, and the per-rank capacity."""
-    per = (n_items + world_size - 1) // world_size
-    i0 = min(rank * per, n_items)
-    return i0, min(i0 + per, n_items), per
-
-
 def colour_rounds(n_spans, ws, per_call_cap=10):
     """The colour loop of `gen_mesh` (`reconstruction.py:58-70`) as rounds: [(first_span, spans_per_rank)].  In a round,
     rank r computes the `spans_per_rank` consecutive calc_normal calls that start at `first_span + r * spans_per_rank`, so

@@ -300,7 +300,7 @@ class PIFuNetwNML(BasePIFuNet):
         flags = (_lib.ENC_ALL_STACKS if self.training else 0) | (_lib.ENC_DEFER_JOIN if _defer else 0)
         if getattr(self, '_direct_trunk', False):           # A/B hook of the tests: the normal nets' trunks as direct convolutions
             flags |= _lib.ENC_NO_WINOGRAD
-        run_f, run_b = use_f, use_b
+        run_f, run_b = use_f, use_b                      # which normal nets the call enables
         if _part in ('F', 'B'):
             run_f, run_b = use_f and _part == 'F', use_b and _part == 'B'
             flags |= _lib.ENC_NORMALS_ONLY
@@ -322,8 +322,7 @@ class PIFuNetwNML(BasePIFuNet):
         stacks = int(o.num_stack) if self.training else 1
         feat = torch.empty(stacks, o.hg_dim, h // 4, w // 4, device=self.device) if _part in (None, 'hourglass') else None
         _lib.call('pifu_filter_coarse', self._ctx.h, _ptr(images), cimg, h, w, int(o.num_stack), int(o.hg_depth),
-                  int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1,
-                  int(run_f if _part in ('F', 'B') else use_f), int(run_b if _part in ('F', 'B') else use_b),
+                  int(o.hg_dim), _ENC_NORM[(o.norm, bool(self.training))], 1, int(run_f), int(run_b),
                   _ptr(self.nmlF), _ptr(self.nmlB), _ptr(feat), flags, _stream_ptr(self.device))
         if feat is not None:
             self.im_feat_list = [feat[k:k + 1] for k in range(stacks)]
