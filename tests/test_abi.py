@@ -76,6 +76,30 @@ def test_graft_entry_build_passes():
     entry.build()
 
 
+def test_header_binds_from_plain_c(lib, tmp_path):
+    """The boundary is a C ABI: `include/pifuhd_hip.h` compiles as C99 with warnings as errors, a C program links the library,
+    gets the header's ABI version, error codes instead of crashes, and the host-only OBJ writer produces the reference's text
+    (`mesh_util.py:189-198`) - no Python, no C++ and no GPU involved."""
+    import shutil
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    lib.load()
+    libdir = os.path.dirname(lib.LIB_PATH)
+    exe = tmp_path / 'abi_smoke'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'c', 'abi_smoke.c'), '-o', str(exe), '-L', libdir, '-lpifuhd_hip',
+                           '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'])
+    out = tmp_path / 'c.obj'
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == 'abi %d ok' % lib.ABI_VERSION
+    from oracle import pifu_oracle as O
+    import numpy as np
+    v = np.array([[0.0, 0.5, -1.25], [1.0, 2.0, 3.0], [-0.00004, 0.00005, 10.0]])
+    c = np.array([[0.1, 0.2, 0.3], [0.5, 0.5, 0.5], [1.0, 0.0, 0.25]])
+    assert O.obj_text(v, np.array([[0, 1, 2]], np.int32), c) == out.read_text() == open(str(out) + '.2').read()
+
+
 def test_product_never_imports_oracle():
     """No file of the product package imports, loads or links anything under oracle/."""
     pkg = os.path.join(ROOT, 'rgb-d-pifuhd_amd')
