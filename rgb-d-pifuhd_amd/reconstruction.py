@@ -17,6 +17,7 @@ import torch
 
 from numpy.linalg import inv
 
+from . import _lib
 from .mesh_util import ObjFile, copy_stream, pinned_flat as mesh_util_pinned, pinned_rows, reconstruction, save_obj_mesh_with_color
 from .nets import index
 
@@ -28,7 +29,6 @@ def set_host_threads(n):
     """Bound the host worker threads one gen_mesh call starts (OBJ formatting / writing threads of the library, PNG deflate
     bands): for several processes on one host - one per GPU - `os.cpu_count() // ranks`.  0 = default."""
     global HOST_THREADS
-    from . import _lib
     HOST_THREADS = max(int(n), 0)
     _lib.call('pifu_set_host_threads', HOST_THREADS)
 
@@ -101,7 +101,6 @@ def _save_debug_png(path, image_tensor_global, background=False):
 def _prof_read(net, which):
     """(ms, launches, work) of one profiling slot of the net's context, not reset (`pifu_profile_read`; synchronises)."""
     import ctypes as C
-    from . import _lib
     ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
     _lib.call('pifu_profile_read', net._ctx.h, which, C.byref(ms), C.byref(n), C.byref(w), 0)
     return ms.value, n.value, w.value
@@ -187,8 +186,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     # kernel time are read at the phase boundaries - each read synchronises the device, so such a run is for the split, not
     # for the clock
     phases = bool(timings is not None and timings.pop('profile_phases', False))
-    from . import _lib as _l
-    p0 = _prof_read(net, _l.PROF_GEMM) if phases else None
+    p0 = _prof_read(net, _lib.PROF_GEMM) if phases else None
 
     def mark():
         if timings is not None:
@@ -228,7 +226,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
         if not _defer_host:       # A/B timing: the copies waited for at once, as before round 4
             host_copies.wait_all()
         t3 = mark()
-        p3 = _prof_read(net, _l.PROF_GEMM) if phases else None
+        p3 = _prof_read(net, _lib.PROF_GEMM) if phases else None
         n_verts, n_faces = host_copies.n_verts, host_copies.n_faces
         spans = _normal_spans(n_verts)
         if any(r == l for (l, r) in spans):
@@ -313,14 +311,14 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
             host_copies.wait_all()
         if png_thread is not None:
             png_thread.join()
+        exchange_stats = pdist.stats_end() if exchange and timings is not None else {}      # (also when the call failed)
     t5 = time.perf_counter()
     if timings is not None:
         timings.update(filter_s=t1 - t0, png_s=t2 - t1, reconstruction_s=t3 - t2, normals_s=t4 - t3, obj_s=t5 - t4,
                        total_s=t5 - t0, n_verts=n_verts, n_faces=n_faces, colour_rounds=len(rounds))
-        if exchange:
-            timings.update(pdist.stats_end())
+        timings.update(exchange_stats)
         if phases:
-            p5 = _prof_read(net, _l.PROF_GEMM)
+            p5 = _prof_read(net, _lib.PROF_GEMM)
             timings.update(gemm_flop_reconstruction=p3[2] - p0[2], gemm_ms_reconstruction=p3[0] - p0[0],
                            gemm_flop_normals=p5[2] - p3[2], gemm_ms_normals=p5[0] - p3[0])
     return (verts, faces, color) if wants_result else None
@@ -403,7 +401,6 @@ def largest_component(verts, faces, device):
     for an edge nobody else uses opens its component; the faces around an edge that three or more faces share (they
     appear once vertices have been merged) are few and are counted per component here.  Raises IndexError when no
     component is watertight (`cc[0]` on an empty list in the reference)."""
-    from . import _lib
     from .net_util import _ctx_cache
     from .nets import _ptr, _stream_ptr
     dev = torch.device(device)
@@ -473,7 +470,6 @@ def _write_obj_plain(path, verts, faces, colours):
 def esti_color(color, xyz_tensor):
     """`esti_color` (`reconstruction.py:180-229`): color uint16 [V,4], xyz_tensor [1,3,V] (projected vertices); returns the
     colour array with every back-side vertex (z < 0) recoloured from the silhouette.  Runs in `pifu_esti_color`."""
-    from . import _lib
     from .net_util import _ctx_cache
     from .nets import _ptr, _stream_ptr
     xyz = xyz_tensor[0].to(torch.float32).contiguous()
