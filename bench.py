@@ -128,18 +128,44 @@ def mesh_digest(verts, faces, color):
 
 
 def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
-    """gen_mesh wall time on N GPUs: (a) ONE subject, grid evaluation + colour loop sharded (max over ranks);
-    (b) N subjects, one per GPU, no communication (time for all N to finish).  Every rank always takes part in every
-    collective, also after a local failure (reported as an error string), so a bad subject cannot hang the job."""
+    """gen_mesh wall time on N GPUs: (a) ONE subject, grid evaluation + colour loop + encoders sharded (max over ranks);
+    (b) N subjects, one per GPU, no communication (time for all N to finish); (c) BASELINE configs[4].
+
+    A local failure must neither skip a collective the other ranks are in nor leave them waiting for ever.  So: no
+    collective of this function sits inside a try block, every leg ends with `leg_end()` - a barrier on a CONTROL group (gloo,
+    its own sockets) with a timeout - and a rank that failed inside a sharded call (its siblings are then stuck in that
+    call's collectives and will never reach the barrier) runs into the timeout and leaves the process: the launcher ends
+    the job within seconds instead of after the process group's 20 minutes.  A failure that is the same on every rank
+    (marching cubes finding no surface) passes the barrier everywhere and is reported as an error string in the line."""
+    import datetime
     import torch
     from pifuhd_amd import reconstruction as recon
     res = {'resolution': args.genmesh_res, 'use_octree': True, 'n_gpus': world}
     keys = ('filter_s', 'png_s', 'reconstruction_s', 'normals_s', 'obj_s')
+    ctrl = dist.new_group(backend='gloo', timeout=datetime.timedelta(minutes=20))
 
     def reduce_max(vals):
         t = torch.tensor(vals, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
+
+    def guarded(what, fn):
+        try:
+            return fn(), None
+        except Exception as e:
+            log(f'{what} failed on this rank: {e!r}')
+            return None, repr(e)
+
+    def leg_end(what, err, sharded):
+        # ranks that got through their (sharded) call arrive here; a rank whose call failed arrives too - and waits at most
+        # args.leg_timeout seconds for the others, who are either here as well (the failure was the same everywhere) or
+        # stuck inside the call it left
+        try:
+            dist.monitored_barrier(group=ctrl, timeout=datetime.timedelta(seconds=args.leg_timeout if (err and sharded) else 1200))
+        except Exception as e:
+            log(f'{what}: the other ranks did not reach the end of the leg ({e!r}); leaving so that the launcher ends the job')
+            sys.stderr.flush()
+            os._exit(3)
 
     # N processes share this host: where EVERY rank writes a file (the independent subjects) each one's OBJ writer / PNG encoder
     # gets its share of the cores, not all of them; where only rank 0 writes (the sharded legs) it may use the machine
@@ -148,48 +174,59 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds')
 
     with tempfile.TemporaryDirectory() as td:
-        # (a) sharded: identical inputs on every rank, so a failure is the same on every rank.  Rank 0 streams the OBJ and is
-        # the only rank that copies the mesh to the host (result_on='rank0', the default)
-        timings, err, t_tot = {}, None, float('inf')
-        try:
+        # (a) sharded: identical inputs on every rank.  Rank 0 streams the OBJ and is the only rank that copies the mesh to the
+        # host (result_on='rank0', the default)
+        timings = {}
+
+        def leg_a():
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'warm{rank}.obj'), sharded=True)      # at the timed size
-            fence()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'mesh{rank}.obj'), timings=timings, sharded=True)
-            fence()
-            t_tot = time.perf_counter() - t0
-        except Exception as e:
-            err = repr(e)
-        red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys] + [float(timings.get('collective_s', 0.0))])
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            return time.perf_counter() - t0
+        t_tot, err = guarded('gen_mesh sharded', leg_a)
+        leg_end('gen_mesh sharded', err, True)
+        red = reduce_max([t_tot if err is None else float('inf')] + [timings.get(k, float('inf')) for k in keys] +
+                         [float(timings.get('collective_s', 0.0))])
         if err is None and red[0] != float('inf'):
             res['one_subject_sharded'] = {'world': world, 'total_s': round(red[0], 4), **{k: round(v, 4) for k, v in zip(keys, red[1:])},
                                           'n_verts': timings.get('n_verts'), 'n_faces': timings.get('n_faces'),
                                           'result_on': 'rank0',
                                           # rank 0's own view of the exchange: one all-gather of the fp32 predictions per octree
-                                          # level + one of the colours per round; the time between the events around them
-                                          # includes waiting for the slowest rank; max over ranks beside it
+                                          # level + one of the colours per round + the four broadcasts of the dealt-out encoders;
+                                          # the time between the events around them includes waiting for the slowest rank; its
+                                          # max over ranks beside it
                                           **{k: timings.get(k) for k in extra}, 'collective_s_max_over_ranks': round(red[-1], 5)}
             log(f"gen_mesh sharded: {red[0]:.3f} s")
         else:
             res['one_subject_sharded'] = {'error': err or 'failed on another rank'}
-        # (b) independent subjects (different images: a failure may be local to one rank).  One untimed call with the rank's
-        # own image first: the first call with a new mesh size allocates (pinned result slabs, arenas), which is not the
-        # steady state of a recon() loop over many subjects
-        err, t_tot = None, float('inf')
+        # (b) independent subjects (different images: a failure may be local to one rank; the call has no collective, so a
+        # failed rank simply waits for the others at the fences).  One untimed call with the rank's own image first: the first
+        # call with a new mesh allocates (pinned result slabs), which is not the steady state of a recon() loop over many subjects
         recon.set_host_threads(host_threads)
-        try:
-            own = synth.synthetic_inputs(1024, args.image_channels, seed=rank)
+        own = synth.synthetic_inputs(1024, args.image_channels, seed=rank)
+
+        def warm_b():
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subjwarm{rank}.obj'))
             os.remove(os.path.join(td, f'subjwarm{rank}.obj'))
-            fence()
+        _, err = guarded('independent subjects (warm-up)', warm_b)
+        fence()
+
+        def timed_b():
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subj{rank}.obj'))
             torch.cuda.synchronize(dev)
-            t_tot = time.perf_counter() - t0
-        except Exception as e:
-            err = repr(e)
+            return time.perf_counter() - t0
+        t_tot = None
+        if err is None:
+            t_tot, err = guarded('independent subjects', timed_b)
         recon.set_host_threads(0)
-        red = reduce_max([t_tot])
+        leg_end('independent subjects', err, False)
+        red = reduce_max([t_tot if err is None else float('inf')])
         if red[0] != float('inf'):
             res['independent_subjects'] = {'subjects': world, 'total_s': round(red[0], 4), 'subjects_per_s': round(world / red[0], 3),
                                            'warmed': True}
@@ -200,24 +237,29 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         # by calc_normal calls.  The smoother subject (MLP weights at torch's stock scale): its surface is what a trained
         # net's looks like, and its mesh stays in the millions of vertices at this resolution.
         if args.config5_res > 0:
-            timings, err, t_tot, sha = {}, None, float('inf'), 0
-            try:
-                net5 = smoother_subject(args, dev, data)
-                fence()
+            timings = {}
+            net5, err = guarded('config 5 (building the smoother subject)', lambda: smoother_subject(args, dev, data))
+            fence()
+
+            def leg_c():
                 recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'warm5_{rank}.obj'), sharded=True, result_on='all')
-                fence()
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 mesh = recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'mesh5_{rank}.obj'), timings=timings,
                                       sharded=True, result_on='all')      # every rank returns the mesh: their digests are compared
-                fence()
-                t_tot = time.perf_counter() - t0
-                sha = mesh_digest(*mesh)
-                del net5
-            except Exception as e:
-                err = repr(e)
-            red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                return time.perf_counter() - t0, mesh_digest(*mesh)
+            # a rank without the subject cannot take part in the sharded call: its siblings would wait for it - leave at once
             if err is not None:
-                log(f'config 5 failed on this rank: {err}')
+                leg_end('config 5', err, True)
+            out_c, err = guarded('config 5', leg_c)
+            leg_end('config 5', err, True)
+            t_tot, sha = out_c if err is None else (float('inf'), 0)
+            del net5
+            red = reduce_max([t_tot] + [timings.get(k, float('inf')) for k in keys])
             # every rank must hold the same mesh: max(sha) == min(sha) over the ranks (56 bits of the sha256 of vertices,
             # faces and colours)
             t = torch.tensor([sha, -sha], device=dev, dtype=torch.int64)
@@ -255,6 +297,8 @@ def main():
                     help='functional check, never a measurement: initialise the process group (backend nccl = RCCL) even with ONE '
                          'rank and run every collective of the sharded path (all-gather of the field, of the colours, barrier)')
     ap.add_argument('--no-chunk100k', action='store_true', help='skip the extra pass in 100 000-point chunks')
+    ap.add_argument('--leg-timeout', type=float, default=90.0,
+                    help='N > 1: seconds a rank whose sharded gen_mesh call FAILED waits for its siblings before it leaves the job')
     ap.add_argument('--no-calc-normal-leg', action='store_true', help='skip the calc_normal measurement (pixel tables against per-point GEMMs)')
     ap.add_argument('--no-encoder-leg', action='store_true', help='skip the timed encoder passes (roofline_secondary: encoders)')
     ap.add_argument('--no-canonical', action='store_true', help='skip the extra canonical per-point pass (no column sharing)')
