@@ -255,7 +255,9 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             # a rank without the subject cannot take part in the sharded call: its siblings would wait for it - leave at once
             if err is not None:
                 leg_end('config 5', err, True)
-            out_c, err = guarded('config 5', leg_c)
+                out_c = None                       # (every rank failed alike, else this rank has left: the error is reported)
+            else:
+                out_c, err = guarded('config 5', leg_c)
             leg_end('config 5', err, True)
             t_tot, sha = out_c if err is None else (float('inf'), 0)
             del net5
