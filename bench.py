@@ -180,6 +180,8 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
 
         def leg_a():
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'warm{rank}.obj'), sharded=True)      # at the timed size
+            if os.environ.get('PIFU_BENCH_FAIL_IN_LEG') == str(rank):
+                raise RuntimeError('test hook: this rank fails inside the sharded leg')      # tests/test_gpu_dist.py
             torch.cuda.synchronize(dev)
             dist.barrier()
             torch.cuda.synchronize(dev)

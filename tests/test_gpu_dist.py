@@ -307,6 +307,26 @@ def test_bench_a_failed_rank_ends_the_job():
     assert 'test hook' in r.stderr
 
 
+@pytest.mark.timeout(700)
+def test_bench_a_rank_failing_inside_a_sharded_leg_ends_the_job_quickly():
+    """The asymmetric failure the N > 1 legs must survive without hanging: ONE rank raises in the middle of the sharded
+    gen_mesh leg while its sibling is already waiting for it in the next collective.  The failing rank waits `--leg-timeout`
+    seconds on the control group's barrier, finds nobody, and leaves the process; the launcher ends the job (non-zero code,
+    no JSON line) - within seconds, not after the process group's 20-minute timeout."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(PIFU_BENCH_ONE_GPU='1', PIFU_BENCH_FAIL_IN_LEG='1')
+    t0 = time.time()
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--res', '64', '--genmesh-res', '64',
+                        '--config5-res', '0', '--batch-rows', '262144', '--no-cpu-baseline', '--leg-timeout', '10'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert time.time() - t0 < 300
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'test hook: this rank fails inside the sharded leg' in r.stderr and 'leaving so that the launcher ends the job' in r.stderr
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4] as far as one GPU reaches: ONE subject on a 1024^3 grid, two ranks (gloo, both on this box's GPU),
 # octree levels sharded by chunk ranges, marching cubes over one axis-0 slab per rank with dist.SLAB_MC_MIN_RESOLUTION at
