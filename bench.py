@@ -132,17 +132,16 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     (b) N subjects, one per GPU, no communication (time for all N to finish); (c) BASELINE configs[4].
 
     A local failure must neither skip a collective the other ranks are in nor leave them waiting for ever.  So: no
-    collective of this function sits inside a try block, every leg ends with `leg_end()` - a barrier on a CONTROL group (gloo,
-    its own sockets) with a timeout - and a rank that failed inside a sharded call (its siblings are then stuck in that
+    collective of this function sits inside a try block, every leg ends with `leg_end()` - a counter in the rendezvous store
+    that every rank increments and polls, with a timeout - and a rank that failed inside a sharded call (its siblings are then stuck in that
     call's collectives and will never reach the barrier) runs into the timeout and leaves the process: the launcher ends
     the job within seconds instead of after the process group's 20 minutes.  A failure that is the same on every rank
     (marching cubes finding no surface) passes the barrier everywhere and is reported as an error string in the line."""
-    import datetime
     import torch
     from pifuhd_amd import reconstruction as recon
     res = {'resolution': args.genmesh_res, 'use_octree': True, 'n_gpus': world}
     keys = ('filter_s', 'png_s', 'reconstruction_s', 'normals_s', 'obj_s')
-    ctrl = dist.new_group(backend='gloo', timeout=datetime.timedelta(minutes=20))
+    store = dist.distributed_c10d._get_default_store()          # the rendezvous TCPStore: the control plane of the legs
 
     def reduce_max(vals):
         t = torch.tensor(vals, device=dev, dtype=torch.float64)
@@ -156,16 +155,24 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             log(f'{what} failed on this rank: {e!r}')
             return None, repr(e)
 
+    leg_no = [0]
+
     def leg_end(what, err, sharded):
         # ranks that got through their (sharded) call arrive here; a rank whose call failed arrives too - and waits at most
         # args.leg_timeout seconds for the others, who are either here as well (the failure was the same everywhere) or
-        # stuck inside the call it left
-        try:
-            dist.monitored_barrier(group=ctrl, timeout=datetime.timedelta(seconds=args.leg_timeout if (err and sharded) else 1200))
-        except Exception as e:
-            log(f'{what}: the other ranks did not reach the end of the leg ({e!r}); leaving so that the launcher ends the job')
-            sys.stderr.flush()
-            os._exit(3)
+        # stuck inside the call it left.  A counter in the rendezvous store, polled: no collective, nothing to mismatch.
+        leg_no[0] += 1
+        key = f'pifu_bench_leg_{leg_no[0]}'
+        store.add(key, 1)
+        limit = args.leg_timeout if (err and sharded) else 1200.0
+        t0 = time.time()
+        while store.add(key, 0) < world:
+            if time.time() - t0 > limit:
+                log(f'{what}: the other ranks did not reach the end of the leg within {limit:.0f} s; leaving so that the '
+                    f'launcher ends the job')
+                sys.stderr.flush()
+                os._exit(3)
+            time.sleep(0.02)
 
     # N processes share this host: where EVERY rank writes a file (the independent subjects) each one's OBJ writer / PNG encoder
     # gets its share of the cores, not all of them; where only rank 0 writes (the sharded legs) it may use the machine
