@@ -148,6 +148,14 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
+    def rm(path):
+        # the legs' files go as soon as they are no longer needed: a 512^3 OBJ is ~0.5 GB, a 1024^3 one ~0.8 GB, per rank in leg (b)
+        for f in (path, path[:-4] + '.png'):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
     def guarded(what, fn):
         try:
             return fn(), None
@@ -187,6 +195,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
 
         def leg_a():
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'warm{rank}.obj'), sharded=True)      # at the timed size
+            rm(os.path.join(td, f'warm{rank}.obj'))
             if os.environ.get('PIFU_BENCH_FAIL_IN_LEG') == str(rank):
                 raise RuntimeError('test hook: this rank fails inside the sharded leg')      # tests/test_gpu_dist.py
             torch.cuda.synchronize(dev)
@@ -196,7 +205,9 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, f'mesh{rank}.obj'), timings=timings, sharded=True)
             torch.cuda.synchronize(dev)
             dist.barrier()
-            return time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            rm(os.path.join(td, f'mesh{rank}.obj'))
+            return dt
         t_tot, err = guarded('gen_mesh sharded', leg_a)
         leg_end('gen_mesh sharded', err, True)
         red = reduce_max([t_tot if err is None else float('inf')] + [timings.get(k, float('inf')) for k in keys] +
@@ -221,7 +232,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
 
         def warm_b():
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subjwarm{rank}.obj'))
-            os.remove(os.path.join(td, f'subjwarm{rank}.obj'))
+            rm(os.path.join(td, f'subjwarm{rank}.obj'))
         _, err = guarded('independent subjects (warm-up)', warm_b)
         fence()
 
@@ -229,7 +240,9 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             t0 = time.perf_counter()
             recon.gen_mesh(args.genmesh_res, netMR, dev, own, os.path.join(td, f'subj{rank}.obj'))
             torch.cuda.synchronize(dev)
-            return time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            rm(os.path.join(td, f'subj{rank}.obj'))
+            return dt
         t_tot = None
         if err is None:
             t_tot, err = guarded('independent subjects', timed_b)
@@ -252,6 +265,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
 
             def leg_c():
                 recon.gen_mesh(args.config5_res, net5, dev, data, os.path.join(td, f'warm5_{rank}.obj'), sharded=True, result_on='all')
+                rm(os.path.join(td, f'warm5_{rank}.obj'))
                 torch.cuda.synchronize(dev)
                 dist.barrier()
                 torch.cuda.synchronize(dev)
@@ -260,7 +274,9 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                                       sharded=True, result_on='all')      # every rank returns the mesh: their digests are compared
                 torch.cuda.synchronize(dev)
                 dist.barrier()
-                return time.perf_counter() - t0, mesh_digest(*mesh)
+                dt = time.perf_counter() - t0
+                rm(os.path.join(td, f'mesh5_{rank}.obj'))
+                return dt, mesh_digest(*mesh)
             # a rank without the subject cannot take part in the sharded call: its siblings would wait for it - leave at once
             if err is not None:
                 leg_end('config 5', err, True)
@@ -808,6 +824,12 @@ def main():
         from pifuhd_amd import mesh_util, reconstruction as recon
         with tempfile.TemporaryDirectory() as td:
             timings = {}
+
+            def drop(name):      # a 512^3 OBJ is ~0.5 GB, a 1024^3 one ~0.8 GB: gone as soon as its call has been timed
+                try:
+                    os.remove(os.path.join(td, name))
+                except OSError:
+                    pass
             try:
                 # warm-up at the timed size: the marching-cubes arena, the octree state and the pinned result buffers of a
                 # 512^3 mesh are allocated here, as they are for every subject after the first one of a recon() loop
@@ -815,6 +837,7 @@ def main():
                 w0 = time.perf_counter()
                 recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm.obj'))
                 torch.cuda.synchronize(dev)
+                drop('warm.obj')
                 cold['first_gen_mesh_call_s'] = round(time.perf_counter() - w0, 4)
                 log(f"gen_mesh warm-up done (first call at this size: {cold['first_gen_mesh_call_s']} s)")
                 reset_prof(_lib, h)
@@ -930,8 +953,10 @@ def main():
                 try:
                     _lib.call('pifu_set_precision', h, 2)
                     recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm_fp16x3.obj'))
+                    drop('warm_fp16x3.obj')
                     ts = {}
                     recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'mesh_fp16x3.obj'), timings=ts)
+                    drop('mesh_fp16x3.obj')
                     out['gen_mesh']['opt_in_fp16x3'] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ts.items()}
                     log(f"gen_mesh with fp16x3 split products (opt-in): {ts.get('total_s'):.3f} s, {ts.get('n_verts')} vertices")
                 except Exception as e:
@@ -947,8 +972,10 @@ def main():
                     netMR2 = smoother_subject(args, dev, data)
                     # warm-up at the timed size: this context's workspaces grow here, not inside the timed call
                     recon.gen_mesh(args.genmesh_res, netMR2, dev, data, os.path.join(td, 'warm2.obj'))
+                    drop('warm2.obj')
                     t2 = {}
                     recon.gen_mesh(args.genmesh_res, netMR2, dev, data, os.path.join(td, 'mesh2.obj'), timings=t2)
+                    drop('mesh2.obj')
                     out['gen_mesh']['smoother_subject'] = {
                         'mlp_weight_std': 0.02, **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t2.items()}}
                     log(f"gen_mesh, smoother subject: {t2.get('total_s'):.3f} s, {t2.get('n_verts')} vertices")
@@ -956,8 +983,10 @@ def main():
                     if args.config5_res > 0:
                         try:
                             recon.gen_mesh(args.config5_res, netMR2, dev, data, os.path.join(td, 'warm5.obj'))
+                            drop('warm5.obj')
                             t5 = {}
                             m5 = recon.gen_mesh(args.config5_res, netMR2, dev, data, os.path.join(td, 'mesh5.obj'), timings=t5)
+                            drop('mesh5.obj')
                             out['gen_mesh']['config5_1024'] = {
                                 'resolution': args.config5_res, 'subject': 'smoother (mlp_weight_std 0.02)', 'n_gpus': 1,
                                 **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t5.items()},
@@ -1010,6 +1039,7 @@ def main():
                     normals_s = (c3 - c2) * (len(cv) / max(done_v, 1))          # extrapolated when the loop was cut short
                     gt = {}
                     recon.gen_mesh(Rc, netMR, dev, data, os.path.join(td, 'same_res.obj'), timings=gt)
+                    drop('same_res.obj')
                     # the composition on the device against the composition on the host: the float64 SDF of the whole
                     # multi-level octree (network field), the points each evaluated, and the mesh
                     sdf_g, n_gpu = mesh_util.eval_grid_device(netMR, calib, Rc, 5000, True)
