@@ -557,7 +557,8 @@ def main():
             'traffic': (prof_json.get('detail', {}).get('k_walk') or {}).get('hbm_bytes_per_launch'),
             'traffic_source': traffic_src,
             'note': 'not at the HBM rate: ~1 000 sign flips per 256-row column segment with the name-seeded weights, each a rank-1 '
-                    'update of (P, R) in double per output - the kernel is bound by fp64 FMA issue first, by the y1 writes second'})
+                    'update of (P, R) in double per output that fetches a 2 KB row of W1^T from L2 (~17 GB of L2 reads per launch): '
+                    'the kernel sits on the L2 (tools/walk_variants.py: outputs per thread / prefetch depth do not move it)'})
     if world == 1 and not args.no_canonical and not args.no_column_sharing:
         try:
             cflags = flags | _lib.Q_NO_COLUMN_SHARING

@@ -1814,6 +1814,9 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 else if (wv == 5) hipLaunchKernelGGL((k_walk<32, 1>), dim3(nseg, N1 / 256), dim3(256), 0, st, wa);
                 else if (wv == 6) hipLaunchKernelGGL((k_walk_pair<16>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
                 else if (wv == 8) hipLaunchKernelGGL((k_walk<32, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
+                else if (wv == 9 && N1 % 512 == 0) hipLaunchKernelGGL((k_walk<16, 4, 128>), dim3(nseg, N1 / 512), dim3(128), 0, st, wa);
+                else if (wv == 10 && N1 % 512 == 0) hipLaunchKernelGGL((k_walk<8, 4, 128>), dim3(nseg, N1 / 512), dim3(128), 0, st, wa);
+                else if (wv == 11 && N1 % 256 == 0) hipLaunchKernelGGL((k_walk<16, 2, 128>), dim3(nseg, N1 / 256), dim3(128), 0, st, wa);
                 else
 #endif
                 if (N1 % 512 == 0) hipLaunchKernelGGL((k_walk<16, 2>), dim3(nseg, N1 / 512), dim3(256), 0, st, wa);
