@@ -467,6 +467,35 @@ def test_result_pool_is_bounded_and_can_be_released():
         mesh_util.POOL_MAX_BYTES = saved
 
 
+def test_result_pool_makes_room_for_growing_results():
+    """Subjects of growing size: once POOL_MAX_SLABS slabs exist and all of them are free but too small, the next result must
+    not fall back to the pageable, synchronous copy for the rest of the process (the round-4 advisor's finding) - the pool
+    drops its smallest free slabs and allocates one that fits, so `to_host_async` keeps returning an event."""
+    import gc
+    from pifuhd_amd import mesh_util
+    mesh_util.release_pinned()
+    src = torch.arange(96 << 20, dtype=torch.uint8, device='cuda')
+    sizes = [6 << 20, 8 << 20, 10 << 20, 12 << 20, 14 << 20, 16 << 20]                # six slabs, all in use at once
+    held = [mesh_util.to_host(src[:n]) for n in sizes]
+    assert len(mesh_util._slabs) == mesh_util.POOL_MAX_SLABS == 6
+    del held
+    gc.collect()
+    # every slab is free, none holds 40 MiB, none is more than four times too large for it to be given back on sight
+    arr, ev = mesh_util.to_host_async(src[:40 << 20])
+    assert ev is not None, 'fell back to the pageable copy although free slabs could make room'
+    ev.synchronize()
+    assert np.array_equal(arr[-5:], src[(40 << 20) - 5:40 << 20].cpu().numpy())
+    assert len(mesh_util._slabs) <= mesh_util.POOL_MAX_SLABS and any(s[0].numel() >= (40 << 20) for s in mesh_util._slabs)
+    # a slab still in use is never dropped to make room
+    arr2, ev2 = mesh_util.to_host_async(src[:80 << 20])
+    assert ev2 is not None
+    ev2.synchronize()
+    assert np.array_equal(arr[:9], np.arange(9, dtype=np.uint8)) and np.array_equal(arr2[:9], np.arange(9, dtype=np.uint8))
+    del arr, arr2
+    gc.collect()
+    mesh_util.release_pinned()
+
+
 def test_gen_mesh_failure_leaves_no_png_thread_behind(tmp_path):
     """gen_mesh starts the PNG encoder on a thread that reads a pinned buffer of this (device, thread).  When the call fails
     after that - here marching cubes finds no surface, reconstruction() returns -1 and the tuple-unpack raises TypeError like
