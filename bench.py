@@ -164,6 +164,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
             return None, repr(e)
 
     leg_no = [0]
+    scratch = []                # the legs' temporary directory: removed by hand where the process is left with os._exit
 
     def leg_end(what, err, sharded):
         # ranks that got through their (sharded) call arrive here; a rank whose call failed arrives too - and waits at most
@@ -179,6 +180,9 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                 log(f'{what}: the other ranks did not reach the end of the leg within {limit:.0f} s; leaving so that the '
                     f'launcher ends the job')
                 sys.stderr.flush()
+                import shutil
+                for d in scratch:
+                    shutil.rmtree(d, ignore_errors=True)
                 os._exit(3)
             time.sleep(0.02)
 
@@ -189,6 +193,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds')
 
     with tempfile.TemporaryDirectory() as td:
+        scratch.append(td)
         # (a) sharded: identical inputs on every rank.  Rank 0 streams the OBJ and is the only rank that copies the mesh to the
         # host (result_on='rank0', the default)
         timings = {}
