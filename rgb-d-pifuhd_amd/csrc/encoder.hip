@@ -921,7 +921,7 @@ struct EncState {
     int norm = 0;                                // 0 batch-eval, 1 batch-train, 2 group, 3 instance (normal nets)
     bool fuse_stats = false;                     // the convs of the net being run leave statistics partials for the next norm
     bool direct_trunk = false;                   // PIFU_ENC_NO_WINOGRAD: the ResnetBlock trunks as direct convolutions
-    bool wino_configured = false;                // k_wino_bridge's dynamic LDS size has been set on this context's device
+    int wino_state = 0;                          // k_wino_bridge's LDS request on this context's device: 0 not asked, 1 granted, -1 refused
     pifu_ctx *ctx = nullptr;                     // owner (pifu_profile_*: algorithmic FLOPs of the convolutions, slot PIFU_PROF_ENC)
     std::string err;
 };
@@ -1474,15 +1474,22 @@ void wino_gemm(EncState &S, const float *V, const float *U, float *M, int T, int
     book_conv(S, 2.0 * 16.0 * T * (double)c * c, 2.0 * H * W * (double)c * c * 9.0);
 }
 
+// k_wino_bridge keeps the plane of 16 channels in LDS: more than the 64 KB a kernel gets by default.  Asked for once per
+// context (i.e. per device); where the device refuses, the trunk stays on the direct convolutions.
+bool wino_available(EncState &S)
+{
+    if (S.wino_state == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino_bridge),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        S.wino_state = e == hipSuccess ? 1 : -1;
+    }
+    return S.wino_state > 0;
+}
+
 void wino_bridge(EncState &S, const WinoArgs &wa)
 {
     const size_t lds = (size_t)wa.H * wa.W * WPX * 4 + 4 * WCG * 2 * sizeof(double) + 2 * WCG * sizeof(float);
-    if (!S.wino_configured) {          // per context, i.e. per device: the plane of 16 channels needs more than the default 64 KB
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wino_bridge), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess)
-            throw Fail{"k_wino_bridge: cannot reserve its LDS"};
-        S.wino_configured = true;
-    }
     hipLaunchKernelGGL(k_wino_bridge, dim3(wa.C / WCG), dim3(256), lds, S.cur->st, wa);
 }
 
@@ -1506,7 +1513,7 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     hipLaunchKernelGGL(k_affine_act, dim3(nblk(r.pixels() * (c / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, act.scale,
                        act.shift, 0.f, r.p, r.ld, c, r.pixels());
     const ConvGeom gr{3, 1, 1, true};
-    if (wino_ok(r, c) && !S.direct_trunk) {
+    if (wino_ok(r, c) && !S.direct_trunk && wino_available(S)) {
         // the trunk through Winograd: `r` is the residual stream (updated in place by every block), V / M the transformed
         // input and the products of the convolution in flight (one buffer each: the launches are stream-ordered)
         const int T = (r.H / 2) * (r.W / 2);
