@@ -1,14 +1,15 @@
 """Per-launch timeline of ONE steady-state encoder call from a rocprofv3 kernel trace of this script: every launch of
 `filter_local` (default) or `filter_global` in issue order with its grid and duration, then totals by kernel.
     rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/encoder_layers.py [local|global]
-    python tools/encoder_layers.py --report OUT/*/*_kernel_trace.csv"""
+    [PACKS_BACK=2] python tools/encoder_layers.py --report OUT/*/*_kernel_trace.csv"""
 import os, sys
 if len(sys.argv) > 2 and sys.argv[1] == '--report':
     import csv, collections
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r['Start_Timestamp']))
     def short(n): return n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
     packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_input')]
-    seq = rows[packs[-1]:]
+    back = int(os.environ.get('PACKS_BACK', '1'))          # 2 with `global`: from the normal nets' packed input on
+    seq = rows[packs[-back]:]
     t0 = int(seq[0]['Start_Timestamp'])
     acc = collections.Counter()
     for r in seq:
