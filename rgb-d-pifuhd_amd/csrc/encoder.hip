@@ -701,8 +701,10 @@ __global__ void k_nhwc_to_nchw(const float *src, int ld, int C, int HW, float *d
 // normalise, ReLU or residual add, reflection pad and the next convolution's input transform.  k_wino_bridge does all of it in
 // one launch, a block per 16 channels with the whole 32 x 32 plane of those channels in LDS: the direct path's split-K reduce,
 // statistics, finalize and prepared-input kernels (and their launches) between two trunk convolutions are gone.
-constexpr int WCG = 16;            // channels per block of the bridge
+constexpr int WCG = 16;            // channels per block of the bridge (64 blocks moving 64-byte rows: 18 - 26 us; 8 -> 128 blocks of 32-byte rows: 21 - 32 us)
 constexpr int WPX = WCG + 4;       // floats per pixel in LDS (padded: neighbouring tiles land in different banks)
+constexpr int WLPT = WCG / 4;      // lanes per tile / pixel: each moves one float4 of the block's channels
+constexpr int WTS = 256 / WLPT;    // tiles / pixels a block works on at a time
 
 // U[p][o][c] = (G g G^T)[p / 4][p % 4] of the 3 x 3 kernel g = w[o][c]
 __global__ void k_wino_weight(const float *w, int co, int ci, float *U)
@@ -747,19 +749,19 @@ __global__ __launch_bounds__(256) void k_wino_bridge(const WinoArgs a)
     float *h = wino_lds;                                           // [H * W][WPX]
     double *red = reinterpret_cast<double *>(wino_lds + (size_t)a.H * a.W * WPX);     // [4 waves][WCG][2]
     float *aff = reinterpret_cast<float *>(red + 4 * WCG * 2);     // [2][WCG] scale | shift
-    const int tid = threadIdx.x, c4 = tid & 3, ts = tid >> 2;      // four lanes cover a tile's 16 channels (64 contiguous bytes)
+    const int tid = threadIdx.x, c4 = tid % WLPT, ts = tid / WLPT;  // WLPT lanes cover a tile's WCG channels (contiguous bytes)
     const int c0 = blockIdx.x * WCG + 4 * c4;
     const int TW = a.W / 2;
     const size_t plane = (size_t)a.T * a.C;
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
 
     if (a.mode == 0) {
-        for (int px = ts; px < a.H * a.W; px += 64)
+        for (int px = ts; px < a.H * a.W; px += WTS)
             *reinterpret_cast<float4 *>(h + px * WPX + 4 * c4) = *reinterpret_cast<const float4 *>(a.R + (size_t)px * a.C + c0);
     } else {
         // output transform A^T m A of every tile (+ bias) into the plane, statistics on the way
         const float4 b = *reinterpret_cast<const float4 *>(a.bias + c0);
-        for (int t = ts; t < a.T; t += 64) {
+        for (int t = ts; t < a.T; t += WTS) {
             float4 m[16];
 #pragma unroll
             for (int p = 0; p < 16; ++p) m[p] = *reinterpret_cast<const float4 *>(a.M + p * plane + (size_t)t * a.C + c0);
@@ -790,9 +792,9 @@ __global__ __launch_bounds__(256) void k_wino_bridge(const WinoArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) { sd[k] += __shfl_xor(sd[k], o); qd[k] += __shfl_xor(qd[k], o); }
+            for (int o = WLPT; o < 64; o <<= 1) { sd[k] += __shfl_xor(sd[k], o); qd[k] += __shfl_xor(qd[k], o); }
         const int lane = tid & 63, wave = tid >> 6;
-        if (lane < 4) {
+        if (lane < WLPT) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 red[((wave * WCG) + 4 * lane + k) * 2] = sd[k];
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(256) void k_wino_bridge(const WinoArgs a)
         __syncthreads();
         // normalise in place: ReLU (the second convolution's input) or the residual add (the block's output)
         const float4 sc = *reinterpret_cast<const float4 *>(aff + 4 * c4), sh = *reinterpret_cast<const float4 *>(aff + WCG + 4 * c4);
-        for (int px = ts; px < a.H * a.W; px += 64) {
+        for (int px = ts; px < a.H * a.W; px += WTS) {
             float4 v = *reinterpret_cast<const float4 *>(h + px * WPX + 4 * c4);
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
             if (a.mode == 1) {
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void k_wino_bridge(const WinoArgs a)
     __syncthreads();
     if (!a.V) return;
     // input transform B^T d B of every 4 x 4 patch (stride 2) of the reflection-padded plane
-    for (int t = ts; t < a.T; t += 64) {
+    for (int t = ts; t < a.T; t += WTS) {
         const int ty = t / TW, tx = t - ty * TW;
         float4 d[4][4];
 #pragma unroll
