@@ -19,6 +19,13 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#define PIFU_API __attribute__((visibility("default")))
+#else
+#define PIFU_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -55,9 +62,11 @@ enum {
     PIFU_Q_NO_COLUMN_SHARING = 8,          /* lattice sources: evaluate every point independently instead of sharing the
                                               image-feature products of an (i, j) column (same result up to fp32
                                               summation order; 26 % more FLOPs) */
-    PIFU_Q_NO_DEPTH_WALK = 16              /* lattice sources: evaluate coarse layer 1 as a per-point GEMM instead of
+    PIFU_Q_NO_DEPTH_WALK = 16,             /* lattice sources: evaluate coarse layer 1 as a per-point GEMM instead of
                                               walking each column along z (layer-0 activations are piecewise linear
                                               in z inside a column; same result up to fp32 rounding) */
+    PIFU_Q_NO_COARSE_MASK = 32             /* the coarse prediction not masked by the bounding box (PIFuNetwNML.calc_normal,
+                                              PIFuNetwNML.py:207-209, differences the raw MLP output) */
 };
 
 /* pifu_filter_coarse flags */
@@ -94,47 +103,56 @@ enum {
  *      pifu_arena_bytes, pifu_set_host_threads, pifu_enc_set_param_device, the PIFU_ENC_NORMALS_* flags and the pifu_comm_* /
  *      pifu_allgather_* calls added;
  *      a context is still used by ONE call at a time, but consecutive calls may be enqueued on different streams without the
- *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call. */
-#define PIFU_ABI_VERSION 4
-const char *pifu_last_error(void);
-int pifu_abi_version(void);
+ *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call.
+ *   5: round 6 - pifu_enc_set_param_device BORROWS the caller's tensor (no copy, no synchronisation; it must outlive the
+ *      registration); pifu_calc_normal_coarse, pifu_reserve_auto and PIFU_Q_NO_COARSE_MASK added; the library exports nothing
+ *      but the PIFU_API entry points of this header (-fvisibility=hidden + export map). */
+#define PIFU_ABI_VERSION 5
+PIFU_API const char *pifu_last_error(void);
+PIFU_API int pifu_abi_version(void);
 
 /* ---- context ------------------------------------------------------------------------------- */
-int pifu_ctx_create(int device, pifu_ctx **out);
-int pifu_ctx_destroy(pifu_ctx *ctx);
+PIFU_API int pifu_ctx_create(int device, pifu_ctx **out);
+PIFU_API int pifu_ctx_destroy(pifu_ctx *ctx);
 /* Pre-size the query workspace for `rows` padded point rows (growth otherwise happens lazily, outside
  * the timed region after the first call).  Synchronises. */
-int pifu_reserve(pifu_ctx *ctx, int64_t rows);
-int64_t pifu_workspace_bytes(pifu_ctx *ctx);
+PIFU_API int pifu_reserve(pifu_ctx *ctx, int64_t rows);
+/* The same, sized from what the device has free NOW (hipMemGetInfo): rows = the largest multiple of 128 not above `max_rows`
+ * whose batch workspace (worst case over the call kinds: lattice with depth walk, point lists with pixel tables) fits into
+ * `share` (0 < share <= 1) of the free memory, at least one 128-row tile.  For several contexts on one device (ranks sharing a
+ * GPU, or beside other work): with share = 0.5 / contexts none of them runs the card out of memory.  Both MLPs must be defined.
+ * *rows_out (may be NULL) receives the choice. */
+PIFU_API int pifu_reserve_auto(pifu_ctx *ctx, int64_t max_rows, double share, int64_t *rows_out);
+PIFU_API int64_t pifu_workspace_bytes(pifu_ctx *ctx);
 /* Bound the query workspace (the arena of one batch of launches, ~12.5 KB per padded point row) to `bytes`; 0 = no bound
  * (default).  A call whose batch would exceed the bound - or whose allocation the device refuses - runs in more, smaller
  * batches of whole chunks instead: the same numbers (a chunk never depends on the batch it runs in), a few per cent slower
  * below ~0.25 M rows.  One chunk is the floor: PIFU_ERR_NOMEM if even that does not fit.  An arena already larger than the
  * bound is released (synchronises).  For devices shared with other work; the marching-cubes, octree and table arenas
  * (R^3-sized) are not covered. */
-int pifu_set_workspace_limit(pifu_ctx *ctx, int64_t bytes);
+PIFU_API int pifu_set_workspace_limit(pifu_ctx *ctx, int64_t bytes);
 /* Bytes one of the context's device arenas holds at the moment (pifu_workspace_bytes is their sum). */
 enum { PIFU_ARENA_QUERY = 0, PIFU_ARENA_MC = 1, PIFU_ARENA_OCTREE = 2, PIFU_ARENA_COLUMN = 3, PIFU_ARENA_PIXEL = 4, PIFU_ARENA_MISC = 5 };
-int64_t pifu_arena_bytes(pifu_ctx *ctx, int which);
+PIFU_API int64_t pifu_arena_bytes(pifu_ctx *ctx, int which);
 /* Host worker threads the library may start per call (the OBJ writer's formatting / writing threads): 0 = as many as the
  * machine has, at most 32 (default).  Process-wide.  For several processes sharing one host (one per GPU): cpu_count / ranks. */
-int pifu_set_host_threads(int n);
+PIFU_API int pifu_set_host_threads(int n);
 
 /* ---- SurfaceClassifier definition: replaces MLP.__init__ / load_state_dict (MLP.py:12-41) ---- */
 /* dims = filter_channels, res_layers = skip-concat layers, merge_layer as passed to MLP() (<=0 means
  * len(dims)/2, MLP.py:25), norm = PIFU_NORM_*.  Level FINE consumes [fine features | coarse phi]. */
-int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, int ndims,
+PIFU_API int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, int ndims,
                     const int32_t *res_layers, int nres, int merge_layer, int norm);
 /* weight [Cout][Cin] (Conv1d k=1 weight squeezed), bias [Cout]; norm_weight/norm_bias [Cout] or NULL
  * (last layer / PIFU_NORM_NONE); running_mean/var only for the batch modes.  Host pointers. */
-int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight, const float *bias,
+PIFU_API int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const float *weight, const float *bias,
                        const float *norm_weight, const float *norm_bias,
                        const float *running_mean, const float *running_var);
 /* Arithmetic of the MLP GEMMs: 0 = exact fp32 MFMA (default, ~1e-6 from the reference); 1 = bf16 x 3 split precision
  * on the bf16 matrix cores (hi*hi + lo*hi + hi*lo, fp32 accumulation; ~1e-5 on the occupancy, inside the 1e-4 contract);
  * 2 = fp16 x 3: the same three products on the fp16 matrix cores with the weight planes scaled by 2^11 (operands good to
  * 2^-22: ~1e-6 on the occupancy; needs |w| < 32 and |activations| < 65504, the first is checked). */
-int pifu_set_precision(pifu_ctx *ctx, int mode);
+PIFU_API int pifu_set_precision(pifu_ctx *ctx, int mode);
 /* Pixel tables for explicit point lists (pifu_query, pifu_calc_normal*) and for lattice sources whose calibration rules out
  * column sharing (x or y depends on k).  index() is linear in the feature map, so the
  * products of the coarse MLP's weights with the sampled image features (layer 0 and the skip connections, MLP.py:58-64) are
@@ -147,15 +165,15 @@ int pifu_set_precision(pifu_ctx *ctx, int mode);
  * mode.  The table (H * W x 1536 floats: 100 MB for the 128^2 map) lives in the context and is rebuilt when the coarse
  * feature map, the coarse MLP or the precision mode changes. */
 #define PIFU_PIXEL_TABLE_MIN_POINTS 16384
-int pifu_set_pixel_tables(pifu_ctx *ctx, int mode);
+PIFU_API int pifu_set_pixel_tables(pifu_ctx *ctx, int mode);
 /* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
  * z_div = z_size of the COARSE net's options. */
-int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);
+PIFU_API int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);
 
 /* ---- feature maps: the output of filter()/filter_global()/filter_local() -------------------- */
 /* feat: device fp32 NCHW [1][C][H][W] (PIFuNetwNML.py:94-97, PIFuMRNet.py:114-117).  Repacked to NHWC
  * inside the context so that one bilinear tap is one contiguous channel row. */
-int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, int H, int W,
+PIFU_API int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, int H, int W,
                       pifu_stream stream);
 
 /* ---- image encoders: filter() / filter_global() / filter_local() -------------------------------------------
@@ -171,19 +189,23 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
  * streams, the hourglass on a third (joined before the call returns unless PIFU_ENC_DEFER_JOIN is given).
  * pifu_filter_fine = PIFuMRNet.filter_local (PIFuMRNet.py:83-118, rect = None): normals (NCHW, Hn x Wn) are
  * resized bilinearly (align_corners) to H x W, concatenated, HGFilter('no_down'); output [1][hg_dim][H/2][W/2]. */
-int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
-/* The same registration for a rank-4 convolution weight that already lives on the device (a checkpoint loaded to the GPU):
- * the library takes its own device copy (stream-ordered on `stream`, which is synchronised) - no host round trip.  Either way
+PIFU_API int pifu_enc_set_param(pifu_ctx *ctx, const char *name, const float *host_data, const int64_t *shape, int rank);
+/* The same registration for a rank-4 convolution weight that already lives on the device (a checkpoint loaded to the GPU).
+ * ABI 5: the tensor is BORROWED, not copied - it must stay valid and unchanged until the parameter is registered again or the
+ * context is destroyed (the 1.5 GB of encoder weights are then held once by the caller, not a second time by the library), and
+ * the call neither copies nor synchronises; `stream` is the stream the tensor was produced on (the library's lanes fork from the
+ * caller's stream, so a pass issued later on that stream is ordered behind it).  Either way
  * the [Cout][Cin][k][k] tensors are repacked into the kernels' K-run layout BY A KERNEL on first use (1.5 GB of weights:
  * milliseconds instead of the 1.7 s a host loop + pageable upload took); vectors (biases, norm parameters, running
- * statistics) go through pifu_enc_set_param, their folding happens on the host. */
-int pifu_enc_set_param_device(pifu_ctx *ctx, const char *name, const float *dev_data, const int64_t *shape, int rank,
+ * statistics) go through pifu_enc_set_param, their folding happens on the host.  Re-registering parameters after a filter pass
+ * synchronises the device ONCE per batch of registrations (the first call pays it). */
+PIFU_API int pifu_enc_set_param_device(pifu_ctx *ctx, const char *name, const float *dev_data, const int64_t *shape, int rank,
                               pifu_stream stream);
-int pifu_enc_clear(pifu_ctx *ctx);
-int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
+PIFU_API int pifu_enc_clear(pifu_ctx *ctx);
+PIFU_API int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, int num_stack, int hg_depth,
                        int hg_dim, int norm, int ave_pool, int use_front, int use_back, float *nmlF, float *nmlB,
                        float *feat_nchw, int flags, pifu_stream stream);
-int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF,
+PIFU_API int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int W, const float *nmlF,
                      const float *nmlB, int Hn, int Wn, int num_stack, int hg_depth, int hg_dim, int norm,
                      float *feat_nchw, pifu_stream stream);
 
@@ -193,7 +215,7 @@ int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, int H, int 
  * of one call: SURVEY C-1); the n points are treated as consecutive calls of `chunk` points, remainder
  * last (mesh_util.py:98-114).  Outputs (device, may be NULL): pred_fine [n] = net.get_preds()[0][0],
  * pred_coarse [n] = netG.preds[0][0], phi [Cphi][n] = netG.phi[0] (only when n <= chunk). */
-int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib, int64_t chunk,
+PIFU_API int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib, int64_t chunk,
                int flags, float *pred_fine, float *pred_coarse, float *phi, pifu_stream stream);
 
 /* ---- lattice evaluation: create_grid + calib^-1 + eval_func (mesh_util.py:12-38,59-74) -------- */
@@ -202,28 +224,28 @@ int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib
  * float32 exactly like mesh_util.py:61-70) and writes fp32 predictions.  The points are the flat
  * indices first, first+1, ... when `index` is NULL, else index[first .. first+count) (device int64).
  * Chunks are cut relative to `first`, so `first` must be a multiple of `chunk` for parity. */
-int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_inv, const float *calib,
+PIFU_API int pifu_eval_lattice(pifu_ctx *ctx, const int32_t res[3], const double *calib_inv, const float *calib,
                       const int64_t *index, int64_t first, int64_t count, int64_t chunk, int flags,
                       float *pred, pifu_stream stream);
 
 /* ---- octree bookkeeping: eval_grid_octree (mesh_util.py:124-187), order-free form */
 /* state: sdf float64 [R^3] and notprocessed uint8 [R^3], both device, caller-owned. */
-int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *notprocessed, pifu_stream stream);
+PIFU_API int pifu_octree_begin(pifu_ctx *ctx, int R, double *sdf, uint8_t *notprocessed, pifu_stream stream);
 /* Ordered (C-order) compaction of lattice(reso) & notprocessed into index_out (device int64, capacity
  * cap); *count_host receives the number of test points.  Call pattern per level: once with index_out = NULL (counting
  * pass; synchronises the stream ONCE to return the count), then with a buffer of that capacity (fill pass: reuses the
  * block counts of the counting pass, launches the compaction only and does not synchronise).  A fill call that does not
  * follow the counting call of the same level recounts and synchronises. */
-int pifu_octree_select(pifu_ctx *ctx, int R, int reso, const uint8_t *notprocessed,
+PIFU_API int pifu_octree_select(pifu_ctx *ctx, int R, int reso, const uint8_t *notprocessed,
                        int64_t *index_out, int64_t cap, int64_t *count_host, pifu_stream stream);
 /* Scatter the evaluated values, clear notprocessed there, then (if reso > 1) the 8-corner min/max test
  * with `threshold` and the inclusive block fill, bit-exact with the reference's sequential loop. */
-int pifu_octree_commit(pifu_ctx *ctx, int R, int reso, double threshold, const int64_t *index,
+PIFU_API int pifu_octree_commit(pifu_ctx *ctx, int R, int reso, double threshold, const int64_t *index,
                        const float *values, int64_t count, double *sdf, uint8_t *notprocessed,
                        pifu_stream stream);
 /* Convenience single-GPU driver of the three calls above + pifu_eval_lattice; dense when
  * init_resolution <= 0 (eval_grid, mesh_util.py:116-120).  *n_evaluated (host) = points evaluated. */
-int pifu_eval_grid(pifu_ctx *ctx, int R, const double *calib_inv, const float *calib, int64_t chunk,
+PIFU_API int pifu_eval_grid(pifu_ctx *ctx, int R, const double *calib_inv, const float *calib, int64_t chunk,
                    int init_resolution, double threshold, int flags, double *sdf, uint8_t *notprocessed,
                    int64_t *n_evaluated, pifu_stream stream);
 
@@ -233,9 +255,9 @@ int pifu_eval_grid(pifu_ctx *ctx, int R, const double *calib_inv, const float *c
  * and triangle counts in the serial scan order; it synchronises and returns the totals, or
  * PIFU_ERR_MC_LEVEL / PIFU_ERR_MC_EMPTY for the two exceptions skimage raises.  pifu_mc_emit then writes
  * verts fp32 [nv][3] (array-axis order) and faces int32 [nf][3] ('descent' order), bit-exact. */
-int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level,
+PIFU_API int pifu_mc_count(pifu_ctx *ctx, const void *volume, int dtype, int n0, int n1, int n2, double level,
                   int64_t *nverts, int64_t *nfaces, pifu_stream stream);
-int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream);
+PIFU_API int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream);
 
 /* ---- the same marching cubes over axis-0 slabs of one volume (one slab per GPU; SURVEY 8e, BASELINE config 5) ----
  * skimage scans cells with axis 0 outermost (mesh_util.py:84), so the cells [z_first, z_first + n0 - 1) of a slab own one
@@ -251,10 +273,10 @@ int pifu_mc_emit(pifu_ctx *ctx, float *verts, int32_t *faces, pifu_stream stream
  *   pifu_mc_slab_faces  - faces int32 [nfaces][3] in mesh-wide vertex numbers; halo_in = the halo_out of the slab below
  *                         (NULL iff z_first == 0).
  * Concatenating the slabs' arrays in slab order gives pifu_mc_emit's output bit for bit. */
-int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, int n0, int n1, int n2, int z_first, double level,
+PIFU_API int pifu_mc_slab_count(pifu_ctx *ctx, const void *slab, int dtype, int n0, int n1, int n2, int z_first, double level,
                        int64_t *nverts, int64_t *nfaces, float *vmin, float *vmax, pifu_stream stream);
-int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base, int32_t *halo_out, pifu_stream stream);
-int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pifu_stream stream);
+PIFU_API int pifu_mc_slab_verts(pifu_ctx *ctx, float *verts, int64_t vert_base, int32_t *halo_out, pifu_stream stream);
+PIFU_API int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pifu_stream stream);
 
 /* ---- the exchange step of the sharded evaluation (the reference is single-device) -------------------------------
  * One process per GPU evaluates a contiguous range of whole chunks of a grid / octree level's point list and ONE all-gather
@@ -266,24 +288,30 @@ int pifu_mc_slab_faces(pifu_ctx *ctx, int32_t *faces, const int32_t *halo_in, pi
  * receives rank r's send [count_per_rank] at row r, enqueued on `stream` (recv + rank * count_per_rank == send is allowed). */
 typedef struct pifu_comm pifu_comm;
 #define PIFU_COMM_ID_BYTES 128
-int pifu_comm_unique_id(uint8_t id[PIFU_COMM_ID_BYTES]);
-int pifu_comm_create(int device, int rank, int world, const uint8_t id[PIFU_COMM_ID_BYTES], pifu_comm **out);
-int pifu_comm_destroy(pifu_comm *comm);
-int pifu_allgather_f32(pifu_comm *comm, const float *send, float *recv, int64_t count_per_rank, pifu_stream stream);
-int pifu_allgather_bytes(pifu_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, pifu_stream stream);
+PIFU_API int pifu_comm_unique_id(uint8_t id[PIFU_COMM_ID_BYTES]);
+PIFU_API int pifu_comm_create(int device, int rank, int world, const uint8_t id[PIFU_COMM_ID_BYTES], pifu_comm **out);
+PIFU_API int pifu_comm_destroy(pifu_comm *comm);
+PIFU_API int pifu_allgather_f32(pifu_comm *comm, const float *send, float *recv, int64_t count_per_rank, pifu_stream stream);
+PIFU_API int pifu_allgather_bytes(pifu_comm *comm, const void *send, void *recv, int64_t bytes_per_rank, pifu_stream stream);
 
 /* ---- per-vertex normals: PIFuMRNet.calc_normal (PIFuMRNet.py:188-243) as used by gen_mesh -------- */
 /* verts: device fp32 [3][n]; every call is ONE GroupNorm batch of 4n points (p, p+dx, p+dy, p+dz
  * interleaved per point); normals: device fp32 [3][n] unit normals; pred4 (device fp32 [4n], may be NULL) receives the
  * unmasked fine occupancies of those 4n points in that order - the tensor `pred` the reference differences
  * (PIFuMRNet.py:223-230) - so that parity can be checked on the values, not only on the direction of their differences. */
-int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
+PIFU_API int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
                      float *normals, float *pred4, pifu_stream stream);
+
+/* PIFuNetwNML.calc_normal (PIFuNetwNML.py:181-218): the same construction on the COARSE net alone - the 4n interleaved points
+ * go through index / DepthNormalizer / the coarse MLP (sigmoid output, NOT masked by the bounding box), normals = -normalize of
+ * the three forward differences (eps 1e-8).  The reference's default delta is 0.1.  pred4 as above (may be NULL). */
+PIFU_API int pifu_calc_normal_coarse(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta,
+                                     float *normals, float *pred4, pifu_stream stream);
 
 /* The colour loop of gen_mesh (reconstruction.py:58-70) in one call: identical to pifu_calc_normal on consecutive
  * slices of `verts_per_call` vertices (the last one shorter) - every slice is its own GroupNorm batch - but several
  * slices share one kernel launch. */
-int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
+PIFU_API int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64_t verts_per_call, const float *calib,
                              float delta, float *normals, float *pred4, pifu_stream stream);
 
 /* ---- vertex back-transform of reconstruction() (mesh_util.py:87-89): verts = (trans_mat[:3,:3] @ verts.T + trans_mat[:3,3:4]).T
@@ -291,19 +319,19 @@ int pifu_calc_normal_chunked(pifu_ctx *ctx, const float *verts, int64_t n, int64
  * trans_mat; out: device double [n][3].  Per component: the three products accumulated by FMA in k order starting from the
  * first product, the translation added last - the order an FMA-capable BLAS dgemm (what numpy's matmul calls) accumulates
  * K = 3 in; a fixed function of its inputs, compared with numpy on whole arrays by the tests. */
-int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream);
+PIFU_API int pifu_transform_verts(pifu_ctx *ctx, const float *verts, int64_t n, const double *mat, double *out, pifu_stream stream);
 
 /* ---- index(feat, uv) as a standalone op (BasePIFuNet.py:11-23; the vertex-colour lookup of gen_mesh_imgColor,
  * reconstruction.py:112-115): bilinear grid_sample, align_corners=True, zero padding.
  * feat: device fp32 NCHW [C][H][W] (batch 1); uv: device fp32 [2][n]; out: device fp32 [C][n]. */
-int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const float *uv, int64_t n,
+PIFU_API int pifu_index(pifu_ctx *ctx, const float *feat_nchw, int C, int H, int W, const float *uv, int64_t n,
                float *out, pifu_stream stream);
 
 /* ---- image half of readDataset.get_item (readData.py:15-29 addrect, :83-86 cv2.resize, :96-104 ToTensor+Normalize):
  * crop rect = (x, y, w, h) of a BGR uint8 image with a zero border where it leaves the image, resize to size x size
  * with cv2.resize's INTER_LINEAR 8-bit fixed-point arithmetic (INTER_AREA 2x2 mean when the crop is exactly
  * 2*size), BGR -> RGB, v/255, (t-0.5)/0.5.  bgr: device u8 [H][W][3]; out: device fp32 [3][size][size]. */
-int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
+PIFU_API int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const int32_t rect[4], int size,
                           float *out, pifu_stream stream);
 
 /* ---- mesh clean-up of gen_mesh_imgColor_plus (reconstruction.py:127-229,325-344) ---------------------------------------
@@ -321,9 +349,9 @@ int pifu_preprocess_image(pifu_ctx *ctx, const uint8_t *bgr, int H, int W, const
  * |y_s - y| ascending, x_s descending) and <= 10 on the right (x_s >= x: |y_s - y| ascending, x_s ascending), ties in
  * vertex order.  Fails with PIFU_ERR_STATE where the reference raises (no silhouette vertex at all / none on either side).
  * Synchronises the stream. */
-int pifu_face_components(pifu_ctx *ctx, const int32_t *faces, int64_t nfaces, int32_t *label, uint8_t *open_edge,
+PIFU_API int pifu_face_components(pifu_ctx *ctx, const int32_t *faces, int64_t nfaces, int32_t *label, uint8_t *open_edge,
                          pifu_stream stream);
-int pifu_esti_color(pifu_ctx *ctx, const float *xyz, int64_t n, uint16_t *color, pifu_stream stream);
+PIFU_API int pifu_esti_color(pifu_ctx *ctx, const float *xyz, int64_t n, uint16_t *color, pifu_stream stream);
 
 /* ---- supervised forward: CustomBCELoss.forward (net_util.py:45-66) as used by PIFuMRNet.get_error (PIFuMRNet.py:253-274).
  * Forward value only (the HIP path has no autograd): mean over [batch][n] of
@@ -331,7 +359,7 @@ int pifu_esti_color(pifu_ctx *ctx, const float *xyz, int64_t n, uint16_t *color,
  * pred, gt: device fp32 [batch][n]; gamma: device fp32 [batch], or NULL to use fixed_gamma (the loss object's own gamma);
  * w: NULL (no weighting), device fp32 [batch] (w_per_element = 0) or [batch][n] (w_per_element = 1); out: device fp32 [1].
  * Deterministic (fixed-order double accumulation). */
-int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, int64_t n, const float *gamma,
+PIFU_API int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, int64_t n, const float *gamma,
                   float fixed_gamma, const float *w, int w_per_element, int brock, float *out, pifu_stream stream);
 
 /* ---- measurement hook (bench.py / profiles): HIP-event timing, on the launch stream, of the kernels bench.py prices
@@ -349,17 +377,17 @@ int pifu_bce_loss(pifu_ctx *ctx, const float *pred, const float *gt, int batch, 
  * pifu_profile_read synchronises the device and returns, since the last reset: summed kernel time (ms), launches, work. */
 enum { PIFU_PROF_GEMM = 0, PIFU_PROF_SAMPLER = 1, PIFU_PROF_MC = 2, PIFU_PROF_ENC = 3, PIFU_PROF_MC_NODES = 4, PIFU_PROF_WALK = 5,
        PIFU_PROF_ENC_CANONICAL = 6 };
-int pifu_profile_enable(pifu_ctx *ctx, int on);
-int pifu_profile_read(pifu_ctx *ctx, int which, double *ms, int64_t *launches, double *work, int reset);
+PIFU_API int pifu_profile_enable(pifu_ctx *ctx, int on);
+PIFU_API int pifu_profile_read(pifu_ctx *ctx, int which, double *ms, int64_t *launches, double *work, int reset);
 
 /* pifu_clock_probe synchronises the stream and returns, per XCD (8 on MI355X), the shader-clock counter (s_memtime)
  * and the constant 100 MHz real-time counter (s_memrealtime) read by one wave on that XCD: out[2 * xcd] = shader ticks,
  * out[2 * xcd + 1] = real-time ticks (0, 0 for an XCD no probe wave landed on).  Two probes around a timed region give
  * the AVERAGE shader clock the region actually ran at (bench.py reports it beside the nominal-clock roofline). */
-int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream stream);
+PIFU_API int pifu_clock_probe(pifu_ctx *ctx, uint64_t out[16], pifu_stream stream);
 
 /* ---- OBJ writer: save_obj_mesh_with_color (mesh_util.py:189-198); host buffers ------------------ */
-int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
+PIFU_API int pifu_write_obj(const char *path, const double *verts, const double *colors, int64_t nverts,
                    const int32_t *faces, int64_t nfaces);
 /* The same file in two calls, for callers that know the triangles before the vertex colours (gen_mesh: marching cubes, then
  * the colour loop, reconstruction.py:56-72): pifu_obj_begin starts formatting the face lines on worker threads, in memory
@@ -368,7 +396,7 @@ int pifu_write_obj(const char *path, const double *verts, const double *colors, 
  * vertex lines, writes vertices then faces, closes the file and frees the writer (also when it returns an error).
  * nverts < 0 abandons the writer: the workers are joined, nothing is created or truncated - a run that fails between the
  * two calls leaves `path` as it was, like the reference, which only writes once the colours exist. */
-int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride, void **writer);
+PIFU_API int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64_t row_stride, int64_t col_stride, void **writer);
 /* Optional middle steps, for callers that know every vertex POSITION long before the last COLOUR (gen_mesh: marching cubes,
  * then the colour loop, reconstruction.py:56-72).  pifu_obj_layout declares the complete arrays - verts HOST double [nverts][3],
  * colors HOST float32 [nverts][3] (the float32 values the reference copies into its float64 colour array: the same text), both
@@ -378,9 +406,9 @@ int pifu_obj_begin(const char *path, const int32_t *faces, int64_t nfaces, int64
  * formatted and written while the caller computes the rest.  The text goes to `<path>.part`; pifu_obj_finish(writer, NULL,
  * NULL, 0) declares every colour valid, waits, and renames it to `path` (a line whose length was not the predicted one - a NaN
  * or negative colour - makes it rewrite the file in one pass first); nverts < 0 removes the partial file. */
-int pifu_obj_layout(void *writer, const double *verts, const float *colors, int64_t nverts);
-int pifu_obj_ready(void *writer, int64_t upto);
-int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts);
+PIFU_API int pifu_obj_layout(void *writer, const double *verts, const float *colors, int64_t nverts);
+PIFU_API int pifu_obj_ready(void *writer, int64_t upto);
+PIFU_API int pifu_obj_finish(void *writer, const double *verts, const double *colors, int64_t nverts);
 
 #ifdef __cplusplus
 }

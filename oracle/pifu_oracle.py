@@ -214,6 +214,35 @@ class OracleNets:
                        pred[..., 3] - pred[..., 0]], 1)
         return F.normalize(-d, dim=1, eps=1e-8)
 
+    # ---- C-9: the coarse net's own calc_normal / get_error (PIFuNetwNML.py:181-243) ---------------
+    def calc_normal_coarse(self, points, calib, delta=0.1, return_pred=False):
+        """`PIFuNetwNML.calc_normal`: forward differences of the coarse MLP's UNMASKED output over the 4n interleaved
+        points [p, p+dx, p+dy, p+dz] (one MLP call: one GroupNorm batch); points [1,3,n] -> `nml` [1,3,n]."""
+        oc = self.oc
+        n = points.shape[2]
+        stack = [points.clone() for _ in range(4)]
+        for a in range(3):
+            stack[a + 1][:, a, :] += delta
+        pts_all = torch.stack(stack, 3).reshape(points.shape[0], 3, 4 * n)
+        xyz = orthogonal(pts_all, calib)
+        feat = torch.cat([index(self.feat_coarse, xyz[:, :2, :]), depth_feature(xyz, oc.loadSize, oc.z_size)], 1)
+        dims = oc.mlp_dim
+        pred, _ = mlp_forward(self.sd, 'netG.mlp', feat, len(dims) - 1, oc.mlp_res_layers,
+                              effective_merge_layer(oc.merge_layer, dims), oc.mlp_norm, False)
+        p4 = pred.reshape(points.shape[0], 1, n, 4)
+        d = torch.cat([p4[..., 1] - p4[..., 0], p4[..., 2] - p4[..., 0], p4[..., 3] - p4[..., 0]], 1)
+        nml = F.normalize(-d, dim=1, eps=1e-8)
+        return (nml, pred) if return_pred else nml
+
+    def get_error_coarse(self, points, calib, labels, gamma):
+        """`netG.query(points, calib, labels=labels)` + `netG.get_error(gamma)` with CustomBCELoss, eval mode (one stack):
+        labels masked by the x-y-z box (`PIFuNetwNML.py:115-120`), the criterion with a scalar gamma (`:233-236`)."""
+        xyz = orthogonal(points, calib)
+        inside = ((xyz >= -1) & (xyz <= 1)).all(dim=1, keepdim=True).float()
+        pred, _ = self.query_coarse(points, calib)
+        masked = inside * labels
+        return custom_bce_loss(pred, masked, torch.tensor([float(gamma)])), masked
+
     # ---- A7-A10 ---------------------------------------------------------------------------
     def filter_global(self, img_512):
         oc = self.oc

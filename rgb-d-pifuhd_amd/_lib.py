@@ -10,13 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libpifuhd_hip.so')
 
-ABI_VERSION = 4          # PIFU_ABI_VERSION of include/pifuhd_hip.h this binding was written against
+ABI_VERSION = 5          # PIFU_ABI_VERSION of include/pifuhd_hip.h this binding was written against
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_MC_LEVEL, ERR_MC_EMPTY = -1, -2, -3, -4, -5, -6
 LEVEL_COARSE, LEVEL_FINE = 0, 1
 NORM_NONE, NORM_GROUP, NORM_BATCH_EVAL, NORM_BATCH_TRAIN = 0, 1, 2, 3
 PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC, PROF_MC_NODES, PROF_WALK, PROF_ENC_CANONICAL = 0, 1, 2, 3, 4, 5, 6
-Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK = 1, 2, 4, 8, 16
+Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK, Q_NO_COARSE_MASK = 1, 2, 4, 8, 16, 32
 ENC_ALL_STACKS, ENC_DEFER_JOIN, ENC_NORMALS_ONLY, ENC_NORMALS_GIVEN, ENC_NO_WINOGRAD = 1, 2, 4, 8, 16
 PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables
 PIXEL_TABLE_MIN_POINTS = 16384            # the automatic threshold: max(this, H * W of the coarse map) points per call
@@ -44,6 +44,7 @@ SIGNATURES = {
     'pifu_ctx_create': (_i32, [_i32, C.POINTER(_p)]),
     'pifu_ctx_destroy': (_i32, [_p]),
     'pifu_reserve': (_i32, [_p, _i64]),
+    'pifu_reserve_auto': (_i32, [_p, _i64, _d, C.POINTER(_i64)]),
     'pifu_workspace_bytes': (_i64, [_p]),
     'pifu_set_workspace_limit': (_i32, [_p, _i64]),
     'pifu_arena_bytes': (_i64, [_p, _i32]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     'pifu_mc_slab_verts': (_i32, [_p, _p, _i64, _p, _p]),
     'pifu_mc_slab_faces': (_i32, [_p, _p, _p, _p]),
     'pifu_calc_normal': (_i32, [_p, _p, _i64, _p, _f, _p, _p, _p]),
+    'pifu_calc_normal_coarse': (_i32, [_p, _p, _i64, _p, _f, _p, _p, _p]),
     'pifu_calc_normal_chunked': (_i32, [_p, _p, _i64, _i64, _p, _f, _p, _p, _p]),
     'pifu_index': (_i32, [_p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     'pifu_preprocess_image': (_i32, [_p, _p, _i32, _i32, _p, _i32, _p, _p]),

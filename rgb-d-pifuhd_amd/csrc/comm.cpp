@@ -3,6 +3,7 @@
 // over RCCL's ncclAllGather.  RCCL is looked up at run time (dlopen) - the copy the process already holds when a framework
 // loaded one (torch ships its own librccl.so), /opt/rocm's otherwise - so the library itself loads without it.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 #include <mutex>
 
@@ -26,6 +27,13 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_why[512] = "";        // dlerror() text of the decisive dlopen attempt, copied when it failed (dlerror() clears on read)
+
+void keep_dlerror()
+{
+    const char *e = dlerror();
+    snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", e && *e ? e : "dlopen gave no reason");
+}
 
 void load_rccl()
 {
@@ -34,9 +42,11 @@ void load_rccl()
     for (const char *n : names)                                            // the copy already in the process, if any
         if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!h)
-        for (const char *n : names)
+        for (const char *n : names) {
             if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+            keep_dlerror();
+        }
+    if (!h && !(h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL))) keep_dlerror();
     if (!h) return;
     g_rccl.handle = h;
     g_rccl.GetUniqueId = (int (*)(NcclId *))dlsym(h, "ncclGetUniqueId");
@@ -51,7 +61,7 @@ int need_rccl(const char *who)
 {
     std::call_once(g_rccl_once, load_rccl);
     PIFU_REQUIRE(g_rccl.ok, PIFU_ERR_STATE, "%s: RCCL (librccl.so) could not be loaded: %s", who,
-                 g_rccl.handle ? "a symbol is missing" : dlerror());
+                 g_rccl.handle ? "a symbol is missing" : g_rccl_why);
     return PIFU_OK;
 }
 

@@ -916,7 +916,8 @@ struct Affine {           // per-channel transform applied by the consumer
 struct HostParam {
     std::vector<float> data;                     // host values (pifu_enc_set_param); empty for pifu_enc_set_param_device
     std::vector<int64_t> shape;
-    float *raw = nullptr;                        // the tensor as given, on the device (owned): what the packing kernels read
+    float *raw = nullptr;                        // the tensor as given, on the device: what the packing kernels read
+    bool owned = false;                          // raw was uploaded by the library from `data` (else: the caller's tensor, borrowed)
     size_t count() const { size_t n = 1; for (int64_t d : shape) n *= (size_t)d; return n; }
 };
 
@@ -952,6 +953,7 @@ struct EncState {
     bool direct_trunk = false;                   // PIFU_ENC_NO_WINOGRAD: the ResnetBlock trunks as direct convolutions
     int wino_state = 0;                          // k_wino_bridge's LDS request on this context's device: 0 not asked, 1 granted, -1 refused
     pifu_ctx *ctx = nullptr;                     // owner (pifu_profile_*: algorithmic FLOPs of the convolutions, slot PIFU_PROF_ENC)
+    bool busy = false;                           // a filter pass was issued since the last device synchronisation of set_param
     std::string err;
 };
 
@@ -1129,6 +1131,7 @@ const float *raw_on_device(EncState &S, const std::string &name, HostParam &w)
     if (w.raw) return w.raw;
     if (w.data.empty()) throw Fail{name + ": parameter has neither host nor device values"};
     if (hipMalloc(&w.raw, w.data.size() * sizeof(float)) != hipSuccess) throw Fail{"hipMalloc failed for " + name};
+    w.owned = true;
     if (hipMemcpyAsync(w.raw, w.data.data(), w.data.size() * sizeof(float), hipMemcpyHostToDevice, S.cur->st) != hipSuccess)
         throw Fail{"upload failed for " + name};
     return w.raw;
@@ -1704,18 +1707,27 @@ static int set_param(pifu_ctx *ctx, const char *name, const float *host, const f
     size_t n = 1;
     for (int i = 0; i < rank; ++i) { hp.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
     PIFU_HIP(hipSetDevice(ctx->device));
+    // Whatever this registration replaces (the library's own upload of the previous values, packed copies derived from them)
+    // may still be read by a filter pass in flight: ONE device synchronisation per batch of registrations - the first call
+    // after a pass was issued pays it, the hundreds that follow in the same weight refresh do not.
+    const auto settle = [&]() -> int {
+        if (S.busy) { PIFU_HIP(hipDeviceSynchronize()); S.busy = false; }
+        return PIFU_OK;
+    };
     auto old = S.params.find(name);
-    if (old != S.params.end() && old->second.raw) {      // a filter pass may still be packing from the previous copy
-        PIFU_HIP(hipDeviceSynchronize());
+    if (old != S.params.end() && old->second.raw && old->second.owned) {
+        const int rc = settle();
+        if (rc) return rc;
         (void)hipFree(old->second.raw);
         old->second.raw = nullptr;
     }
     if (host) hp.data.assign(host, host + n);
     else {
-        // the library's own copy: the caller may free or overwrite its tensor as soon as its stream has passed this point
-        PIFU_HIP(hipMalloc(&hp.raw, n * sizeof(float)));
-        PIFU_HIP(hipMemcpyAsync(hp.raw, dev, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        PIFU_HIP(hipStreamSynchronize(st));            // the packing kernels run on the lanes' streams, later
+        // borrowed: the packing kernels read the caller's tensor when a layer first needs a packed form of it (the first pass
+        // at a given image size), so it must stay valid until the parameter is registered again or the context is destroyed
+        hp.raw = const_cast<float *>(dev);
+        hp.owned = false;
+        (void)st;
     }
     S.params[name] = std::move(hp);
     // drop every packed copy derived from this parameter: keys `<name>...` (packed weights / biases) and keys
@@ -1728,7 +1740,7 @@ static int set_param(pifu_ctx *ctx, const char *name, const float *host, const f
     for (auto it = S.dev.begin(); it != S.dev.end();) {
         const bool hit = it->first.compare(0, nm.size(), nm) == 0 || (!mod.empty() && it->first.compare(0, mod.size(), mod) == 0);
         if (hit) {
-            if (!dropped) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); dropped = true; }   // a filter may still be reading it
+            if (!dropped) { const int rc = settle(); if (rc) return rc; dropped = true; }   // a filter may still be reading it
             (void)hipFree(it->second);
             it = S.dev.erase(it);
         } else ++it;
@@ -1745,7 +1757,7 @@ extern "C" int pifu_enc_clear(pifu_ctx *ctx)
     (void)hipDeviceSynchronize();
     for (auto &kv : it->second->dev) (void)hipFree(kv.second);
     for (auto &kv : it->second->params)
-        if (kv.second.raw) (void)hipFree(kv.second.raw);
+        if (kv.second.raw && kv.second.owned) (void)hipFree(kv.second.raw);
     for (Lane &L : it->second->lanes) {
         if (L.arena.p) (void)hipFree(L.arena.p);
         if (L.splitk.p) (void)hipFree(L.splitk.p);
@@ -1777,6 +1789,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
     PIFU_REQUIRE(!(normals_only && normals_given), PIFU_ERR_INVALID, "pifu_filter_coarse: NORMALS_ONLY and NORMALS_GIVEN exclude each other");
     state_of(ctx).direct_trunk = (flags & PIFU_ENC_NO_WINOGRAD) != 0;
     EncState &S = state_of(ctx);
+    S.busy = true;
     hipStream_t st = (hipStream_t)stream;
     const size_t px = (size_t)H * W;
     int rc = pifu_enc_join(ctx, st);      // an earlier deferred hourglass still owns the map this call replaces
@@ -1869,6 +1882,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     PIFU_REQUIRE(norm >= 0 && norm <= 2 && hg_dim % 4 == 0, PIFU_ERR_INVALID, "pifu_filter_fine: bad norm / hg_dim");
     PIFU_USE(ctx, stream);
     EncState &S = state_of(ctx);
+    S.busy = true;
     const size_t px = (size_t)H * W / 4;      // the hourglass runs at H/2 x W/2
     int rc = begin(ctx, S, 0, px * 4 * (size_t)(3400 + 2600 * num_stack) + ((size_t)320 << 20), (hipStream_t)stream);
     if (rc) return rc;

@@ -1939,7 +1939,9 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                   rows_cap * 4 < ((int64_t)1 << 31);
     }
     // pixel tables (explicit point lists): the coarse level's image-feature products blended from G = W_feat * F
-    const bool want_coarse = pred_coarse != nullptr || (flags & PIFU_Q_FULL_COARSE);
+    // PIFuNetwNML.calc_normal: the normals come from the COARSE net's own (unmasked) occupancies
+    const bool coarse_normals = src_mode == 3 && coarse_only;
+    const bool want_coarse = pred_coarse != nullptr || (flags & PIFU_Q_FULL_COARSE) || coarse_normals;
     const int upto_c = want_coarse ? mc.nlayers : mc.merge_layer + 1;
     // (also lattice sources whose calibration rules out column sharing: x or y depends on k)
     bool pixmode = !colmode && !(flags & PIFU_Q_NO_COLUMN_SHARING) && ctx->pix_mode != 0 &&
@@ -1983,8 +1985,10 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
     float *fine_out = pred_fine;
     if (src_mode == 3) {   // calc_normal consumes the predictions itself
         fine_out = pl.normal_pred;
+        if (coarse_normals) pred_coarse = pl.normal_pred;
         if (normal_pred_out) *normal_pred_out = pl.normal_pred;
     }
+    const int coarse_mask_bit = (flags & PIFU_Q_NO_COARSE_MASK) ? 0 : 1;
     if ((flags & PIFU_Q_FULL_COARSE) && !pred_coarse) pred_coarse = pl.coarse_scratch;
 
     ColTables T;
@@ -2055,7 +2059,7 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                 // worth it only for segments of some length (start values cost 2 C0 N1 MACs per segment)
                 if (nseg > 0 && nseg <= w.maxseg && nseg * 8 <= npts) walk_nseg = (int)nseg;
             }
-            rc = launch_level_col(ctx, 0, pl, T, g, rows, 1, coarse_dst, upto, st, walk_nseg);
+            rc = launch_level_col(ctx, 0, pl, T, g, rows, coarse_mask_bit, coarse_dst, upto, st, walk_nseg);
             if (rc != PIFU_OK) return rc;
             if (fine) {
                 rc = launch_level_col(ctx, 1, pl, T, g, rows, (flags & PIFU_Q_NO_FINE_MASK) ? 0 : 2,
@@ -2082,8 +2086,8 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
             rc = pifu_prof_end(ctx, PIFU_PROF_SAMPLER, es, per_point * (double)npts, st);
             if (rc != PIFU_OK) return rc;
         }
-        if (pixmode) rc = launch_level_col(ctx, 0, pl, T, g, rows, 1, coarse_dst, upto, st, 0, &pxm);
-        else rc = launch_level(ctx, 0, pl, g, rows, pl.mask, 1, coarse_dst, upto, st);
+        if (pixmode) rc = launch_level_col(ctx, 0, pl, T, g, rows, coarse_mask_bit, coarse_dst, upto, st, 0, &pxm);
+        else rc = launch_level(ctx, 0, pl, g, rows, pl.mask, coarse_mask_bit, coarse_dst, upto, st);
         if (rc != PIFU_OK) return rc;
         if (phi && total_chunks == 1) {
             const MlpLayer &lm = mc.layer[mc.merge_layer];
@@ -2099,6 +2103,38 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
         }
     }
     PIFU_HIP(hipGetLastError());
+    return PIFU_OK;
+}
+
+int pifu_reserve_auto(pifu_ctx *ctx, int64_t max_rows, double share, int64_t *rows_out)
+{
+    PIFU_REQUIRE(ctx && max_rows > 0 && share > 0.0 && share <= 1.0, PIFU_ERR_INVALID, "pifu_reserve_auto: bad argument");
+    PIFU_REQUIRE(ctx->mlp[0].defined, PIFU_ERR_STATE, "pifu_reserve_auto: define the MLPs first (the workspace per row follows from them)");
+    PIFU_HIP(hipSetDevice(ctx->device));
+    size_t free_b = 0, total_b = 0;
+    PIFU_HIP(hipMemGetInfo(&free_b, &total_b));
+    const bool fine = ctx->mlp[1].defined;
+    const Mlp &mc = ctx->mlp[0];
+    const bool walk = mc.nlayers >= 3 && !mc.res[1] && mc.layer[0].cout_pad % 256 == 0;
+    // what the arena already holds is reused, not added: it counts as free for this purpose
+    const double budget = share * ((double)free_b + (double)ctx->arena.bytes);
+    int64_t skip_cols = 0;
+    for (int i = 1; i < mc.nlayers; ++i) if (mc.layer[i].cin_feat) skip_cols += round_up(mc.layer[i].cout, BN);
+    const auto need = [&](int64_t rows) {
+        const int64_t chunks = rows / BM;      // worst case: one chunk per tile
+        const size_t a = carve(ctx, nullptr, rows, chunks, fine, 0, walk, -1).bytes;
+        const size_t b = carve(ctx, nullptr, rows, chunks, fine, rows, false, (int)skip_cols).bytes;
+        return (double)(a > b ? a : b);
+    };
+    int64_t lo = 1, hi = round_up(max_rows, BM) / BM;      // in tiles
+    if (need(hi * BM) <= budget) lo = hi;
+    else
+        while (lo + 1 < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (need(mid * BM) <= budget) lo = mid; else hi = mid;
+        }
+    ctx->ws_rows = lo * BM;
+    if (rows_out) *rows_out = ctx->ws_rows;
     return PIFU_OK;
 }
 
@@ -2139,6 +2175,20 @@ int pifu_calc_normal(pifu_ctx *ctx, const float *verts, int64_t n, const float *
     PIFU_REQUIRE(n > 0, PIFU_ERR_INVALID, "pifu_calc_normal: empty vertex batch (the reference raises here too)");
     float *pred4 = nullptr;
     int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * n, PIFU_Q_NO_FINE_MASK,
+                             nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
+    if (rc != PIFU_OK) return rc;
+    return normals_from_pred4(pred4, n, normals, pred4_out, (hipStream_t)stream);
+}
+
+// PIFuNetwNML.calc_normal (PIFuNetwNML.py:181-218): the same finite differences on the COARSE net's occupancies - one query of
+// the 4n interleaved points through the coarse MLP alone, prediction not masked by the bounding box
+int pifu_calc_normal_coarse(pifu_ctx *ctx, const float *verts, int64_t n, const float *calib, float delta, float *normals,
+                            float *pred4_out, pifu_stream stream)
+{
+    PIFU_REQUIRE(ctx && verts && calib && normals, PIFU_ERR_INVALID, "pifu_calc_normal_coarse: null argument");
+    PIFU_REQUIRE(n > 0, PIFU_ERR_INVALID, "pifu_calc_normal_coarse: empty vertex batch (the reference raises here too)");
+    float *pred4 = nullptr;
+    int rc = pifu_query_impl(ctx, 3, verts, 4 * n, nullptr, nullptr, nullptr, 0, calib, 4 * n, PIFU_Q_COARSE_ONLY | PIFU_Q_NO_COARSE_MASK,
                              nullptr, nullptr, nullptr, delta, &pred4, (hipStream_t)stream);
     if (rc != PIFU_OK) return rc;
     return normals_from_pred4(pred4, n, normals, pred4_out, (hipStream_t)stream);

@@ -47,13 +47,18 @@ _native = None
 
 
 def use_native_comm(device):
-    """Create the library's RCCL communicator over the ranks of the initialised process group (collective) and route the
-    device all-gathers of this module through it.  Returns the communicator handle."""
+    """Create the library's RCCL communicator over the ranks of the initialised DEFAULT process group (collective) and route
+    the device all-gathers of this module through it.  Returns the communicator handle.  `device` is resolved to an indexed
+    device once ('cuda' -> the current device), so that tensors - which always carry an index - compare equal to it."""
     import torch.distributed as dist
     from . import _lib
     global _native
     rank, ws = world()
     dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise _lib.PifuError(_lib.ERR_INVALID, 'use_native_comm: RCCL needs a GPU device')
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    dev = torch.device('cuda', idx)
     ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
     if rank == 0:
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
@@ -65,9 +70,15 @@ def use_native_comm(device):
         ident = carrier.cpu()
     raw = (C.c_uint8 * _lib.COMM_ID_BYTES)(*ident.tolist())
     handle = C.c_void_p()
-    _lib.call('pifu_comm_create', dev.index or 0, rank, ws, raw, C.byref(handle))
-    _native = {'h': handle, 'device': dev}
+    _lib.call('pifu_comm_create', idx, rank, ws, raw, C.byref(handle))
+    _native = {'h': handle, 'device': dev, 'calls': 0, 'bytes': 0}
     return handle
+
+
+def native_comm_stats():
+    """(calls, gathered bytes) that went through the library's own communicator since `use_native_comm` (None when it is
+    not active): what a test reads to prove that the C exchange - not torch.distributed - carried the data."""
+    return None if _native is None else (_native['calls'], _native['bytes'])
 
 
 def release_native_comm():
@@ -78,10 +89,16 @@ def release_native_comm():
         _native = None
 
 
-def _all_gather(full, local, group=None):
-    """full [ws * n, ...] <- every rank's local [n, ...] (contiguous tensors of one dtype)."""
+def _is_default_group(group):
     import torch.distributed as dist
-    if _native is not None and full.is_cuda and full.device == _native['device']:
+    return group is None or group is dist.group.WORLD
+
+
+def _all_gather(full, local, group=None):
+    """full [ws * n, ...] <- every rank's local [n, ...] (contiguous tensors of one dtype).  The library's communicator
+    spans the default group only: a call on a sub-group always goes through torch.distributed."""
+    import torch.distributed as dist
+    if _native is not None and full.is_cuda and full.device == _native['device'] and _is_default_group(group):
         from . import _lib
         from .nets import _ptr, _stream_ptr
         assert full.is_contiguous() and local.is_contiguous() and full.numel() == world()[1] * local.numel()
@@ -90,6 +107,8 @@ def _all_gather(full, local, group=None):
         else:
             _lib.call('pifu_allgather_bytes', _native['h'], _ptr(local), _ptr(full), local.numel() * local.element_size(),
                       _stream_ptr(full.device))
+        _native['calls'] += 1
+        _native['bytes'] += full.numel() * full.element_size()
         return
     dist.all_gather_into_tensor(full, local, group=group)
 

@@ -111,7 +111,10 @@ _ENC_NORM = {('batch', False): 0, ('batch', True): 1, ('group', False): 2, ('gro
 
 def _push_encoder_params(ctx, sd, prefix):
     """Register every floating-point parameter / buffer of an encoder with the context: convolution weights that live on the
-    context's device go across as device pointers (no host round trip of the 1.5 GB), everything else as HOST fp32 copies."""
+    context's device go across as device pointers (BORROWED by the library: no second copy of the 1.5 GB, no host round trip),
+    everything else as HOST fp32 copies.  Returns the tensors the library now points at: the caller keeps them alive until the
+    next registration."""
+    keep = []
     for key, t in sd.items():
         if not (key.startswith('image_filter.') or key.startswith('netF.') or key.startswith('netB.')):
             continue
@@ -121,10 +124,12 @@ def _push_encoder_params(ctx, sd, prefix):
             d = t.detach().to(torch.float32).contiguous()
             shape = (C.c_int64 * 4)(*d.shape)
             _lib.call('pifu_enc_set_param_device', ctx.h, (prefix + key).encode(), _ptr(d), shape, 4, _stream_ptr(ctx.device))
+            keep.append(d)
             continue
         a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
         shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
         _lib.call('pifu_enc_set_param', ctx.h, (prefix + key).encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+    return keep
 
 
 def orthogonal(points, calib, transform=None):
@@ -175,6 +180,15 @@ class BasePIFuNet:
     def get_preds(self):
         return self.preds
 
+    def calc_normal(self, points, calibs, transforms=None, delta=0.1):
+        """`BasePIFuNet.calc_normal` (`BasePIFuNet.py:125-134`): a placeholder in the reference (its body is `None`)."""
+        return None
+
+    def get_error(self, gamma=None):
+        """`BasePIFuNet.get_error` (`BasePIFuNet.py:144-148`) calls `self.error_term`, which no class of the reference
+        defines: the call raises AttributeError there, and here."""
+        return self.error_term(self.preds, self.labels, gamma)
+
     def train(self, mode=True):
         self.training = mode
         return self
@@ -191,10 +205,16 @@ class BasePIFuNet:
 class PIFuNetwNML(BasePIFuNet):
     """Coarse level: normal nets + HGFilter + SurfaceClassifier (`PIFuNetwNML.py:17-141`)."""
 
-    def __init__(self, opt, projection_mode='orthogonal', device='cuda'):
+    def __init__(self, opt, projection_mode='orthogonal', device='cuda', criteria=None):
         super().__init__(projection_mode)
         self.name = 'hg_pifu'
         self.opt = opt
+        # the reference's default {'occ': nn.MSELoss()} cannot take get_error's (pred, gt, gamma) call; its training script
+        # passes CustomBCELoss, which is the default here (as in PIFuMRNet)
+        from .net_util import CustomBCELoss
+        self.criteria = criteria if criteria is not None else {'occ': CustomBCELoss()}
+        self.nml = None                  # what calc_normal leaves behind (the reference's attribute name, SURVEY C-9)
+        self.labels_nml = None
         self._ctx_obj = _Ctx(device)
         self.device = self._ctx_obj.device
         self._sd = None
@@ -260,7 +280,7 @@ class PIFuNetwNML(BasePIFuNet):
         ctx = self._ctx_obj
         _push_mlp(ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), int(o.merge_layer), code)
         _lib.call('pifu_set_depth_normalizer', ctx.h, float(o.loadSize // 2), float(o.z_size))
-        _push_encoder_params(ctx, self._sd, '')
+        self._enc_keep = _push_encoder_params(ctx, self._sd, '')      # borrowed by the library until the next push
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):
@@ -377,6 +397,63 @@ class PIFuNetwNML(BasePIFuNet):
             self.intermediate_preds_list = preds
 
 
+    def calc_normal(self, points, calibs, transforms=None, labels=None, delta=0.1, keep_pred=False):
+        """`PIFuNetwNML.calc_normal` (`PIFuNetwNML.py:181-218`): points [1,3,N], calibs [1,4,4] -> `self.nml` [1,3,N], the
+        negated, normalised forward differences (step `delta`, 0.1 by default) of the coarse net's own UNMASKED occupancy;
+        the 4N points [p, p+dx, p+dy, p+dz] go through the MLP as ONE call (one GroupNorm batch), as in the reference.
+        Like the reference it writes `self.nml` - `get_error` reads `self.nmls`, which this method never sets (SURVEY C-9)."""
+        self._check_unsupported(transforms)
+        if not self.im_feat_list:
+            raise _lib.PifuError(_lib.ERR_STATE, 'filter() must precede calc_normal()')
+        if labels is not None:
+            self.labels_nml = labels
+        self._sync_weights()
+        pts = points.to(self.device, torch.float32)
+        if pts.dim() != 3 or pts.shape[0] != 1 or pts.shape[1] != 3:
+            raise NotImplementedError('batch size 1, points [1,3,N] (the reconstruction path)')
+        pts = pts[0].contiguous()
+        n = pts.shape[1]
+        if n == 0:
+            raise RuntimeError('calc_normal on an empty point list')      # Conv1d on an empty tensor raises in the reference
+        if len(self.im_feat_list) > 1:
+            self._set_features(self.im_feat_list[-1])                      # PIFuNetwNML.py:203: the LAST stack's map
+        calib, calib_p = _host_f32(calibs[0])
+        out = torch.empty(3, n, device=self.device, dtype=torch.float32)
+        pred4 = torch.empty(4 * n, device=self.device, dtype=torch.float32) if keep_pred else None
+        _lib.call('pifu_calc_normal_coarse', self._ctx.h, _ptr(pts), n, calib_p, float(delta), _ptr(out), _ptr(pred4),
+                  _stream_ptr(self.device))
+        self.nml = out[None]
+        self.nml_preds = pred4.view(1, 1, n, 4) if keep_pred else None     # `pred` of PIFuNetwNML.py:209, [B, 1, N, 4]
+
+    def get_im_feat(self):
+        """`PIFuNetwNML.get_im_feat` (`PIFuNetwNML.py:220-226`)."""
+        return self.im_feat_list[-1]
+
+    def get_error(self, gamma):
+        """`PIFuNetwNML.get_error` (`PIFuNetwNML.py:228-243`), forward value only: the occupancy criterion averaged over the
+        stacks' predictions with the scalar `gamma`; `Err(nml)` only when `self.nmls` and the normal labels both exist."""
+        if self.labels is None or not self.intermediate_preds_list:
+            raise _lib.PifuError(_lib.ERR_STATE, 'query(..., labels=...) must precede get_error()')
+        g = torch.tensor([float(gamma)])
+        total = 0.0
+        for preds in self.intermediate_preds_list:
+            total = total + self.criteria['occ'](preds, self.labels, g)
+        error = {'Err(occ)': total / len(self.intermediate_preds_list)}
+        if self.nmls is not None and self.labels_nml is not None:
+            error['Err(nml)'] = self.criteria['nml'](self.nmls, self.labels_nml)
+        return error
+
+    def forward(self, images, points, calibs, labels, gamma, points_nml=None, labels_nml=None):
+        """`PIFuNetwNML.forward` (`PIFuNetwNML.py:245-258`), forward-only (no autograd on the HIP path) -> (err, res)."""
+        self.filter(images)
+        self.query(points, calibs, labels=labels)
+        if points_nml is not None and labels_nml is not None:
+            self.calc_normal(points_nml, calibs, labels=labels_nml)
+        return self.get_error(gamma), self.get_preds()
+
+    __call__ = forward
+
+
 class PIFuMRNet(BasePIFuNet):
     """Fine level (`PIFuMRNet.py:15-243`); owns a reference to the coarse net `netG`."""
 
@@ -441,7 +518,7 @@ class PIFuMRNet(BasePIFuNet):
         self.netG._sync_weights()                               # the fine MLP is defined against the coarse one
         ctx = self.netG._ctx_obj
         _push_mlp(ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
-        _push_encoder_params(ctx, self._sd, 'fine.')
+        self._enc_keep = _push_encoder_params(ctx, self._sd, 'fine.')
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):

@@ -26,16 +26,20 @@ def test_header_symbols_exported_and_bound(lib):
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in the header but not exported'
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert handle.pifu_abi_version() == lib.ABI_VERSION == 4
+    assert handle.pifu_abi_version() == lib.ABI_VERSION == 5
 
 
 def test_library_exports_exactly_the_header(lib):
-    """No lab switches or diagnostics in the shipped library: its `pifu_*` exports are the header's declarations."""
+    """No lab switches, diagnostics or C++ internals in the shipped library: its WHOLE dynamic symbol table (every defined
+    symbol `nm -D` lists, not only the `pifu_*` names) is the set of declarations of the header.  The library is built
+    with -fvisibility=hidden, the entry points carry PIFU_API, and the link uses csrc/exports.map."""
     header = open(os.path.join(ROOT, 'include', 'pifuhd_hip.h')).read()
     declared = set(re.findall(r'\b(pifu_[a-z0-9_]+)\s*\(', header)) - {'pifu_ctx', 'pifu_stream', 'pifu_comm'}
+    # every declaration carries the export attribute
+    assert len(re.findall(r'^PIFU_API\s', header, re.M)) == len(declared)
     lib.load()
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH], text=True)
-    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('pifu_')}
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
     assert exported == declared, exported ^ declared
     blob = open(lib.LIB_PATH, 'rb').read()
     for switch in (b'PIFU_GEMM_VARIANT', b'PIFU_COLUMN_MODE', b'PIFU_DEPTH_WALK', b'PIFU_PRECISION', b'PIFU_DEBUG_STAMPS'):

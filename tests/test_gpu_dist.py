@@ -129,13 +129,29 @@ def _rccl_worker(port, outdir):
     # the same collectives through the C ABI's own RCCL communicator (pifu_comm_* / pifu_allgather_*: what a binding without
     # torch.distributed calls); torch.distributed only carries the communicator id
     pdist.SLAB_MC_MIN_RESOLUTION = 1024
-    pdist.use_native_comm('cuda')
-    nat_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
-    nat = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native.obj'), sharded=True, result_on='all')
-    pdist.SLAB_MC_MIN_RESOLUTION = 64                  # float64 / int32 all-gathers go through pifu_allgather_bytes
-    nat_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native_slab.obj'), sharded=True, result_on='all')
+    pdist.use_native_comm('cuda')                      # no index given: resolved to the current device (round-5 advisor)
+    # proof that the C exchange carries the data: while the native communicator is active torch.distributed's all-gather
+    # must not be reached at all, and the communicator counts its own calls
+    torch_gather = dist.all_gather_into_tensor
+
+    def refuse(*a, **k):
+        raise AssertionError('torch.distributed.all_gather_into_tensor reached while the native communicator is active')
+    dist.all_gather_into_tensor = refuse
+    try:
+        nat_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
+        calls_field = pdist.native_comm_stats()[0]
+        nat = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native.obj'), sharded=True, result_on='all')
+        calls_mesh = pdist.native_comm_stats()[0]
+        pdist.SLAB_MC_MIN_RESOLUTION = 64              # float64 / int32 all-gathers go through pifu_allgather_bytes
+        nat_slab = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, 'native_slab.obj'), sharded=True, result_on='all')
+        calls_slab, bytes_all = pdist.native_comm_stats()
+    finally:
+        dist.all_gather_into_tensor = torch_gather
     pdist.release_native_comm()
-    native_ok = (torch.equal(want_field, nat_field) and all(np.array_equal(a, b) for a, b in zip(want, nat))
+    # one all-gather for the dense field; octree levels + colour rounds for the mesh; four more per slab marching cubes
+    native_ran = calls_field == 1 and calls_mesh >= calls_field + 3 and calls_slab >= calls_mesh + (calls_mesh - calls_field) + 4 \
+        and bytes_all > 0
+    native_ok = (native_ran and torch.equal(want_field, nat_field) and all(np.array_equal(a, b) for a, b in zip(want, nat))
                  and all(np.array_equal(a, b) for a, b in zip(want, nat_slab))
                  and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'native.obj')).read())
     t = torch.tensor([3.0], device='cuda')

@@ -728,3 +728,44 @@ def test_workspace_limit_runs_smaller_batches_with_identical_results():
     again = run_all()
     for a, b in zip(want, again):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('tag,mlp_norm', [('group', 'group'), ('batch', 'batch'), ('none', 'no')])
+def test_coarse_net_standalone_api_matches_reference(golden_dir, observed, tag, mlp_norm):
+    """`PIFuNetwNML.calc_normal` / `get_im_feat` / `get_error` / `forward`'s occupancy term (`PIFuNetwNML.py:181-258`,
+    SURVEY C-9) against the fixture of the imported reference (`tests/golden/make_golden_r6.py`): the 4N unmasked coarse
+    occupancies the method differences by VALUE (1e-4), the normals where the differences are not rounding noise, through
+    the per-point GEMMs and through the pixel tables; `calc_normal` writes `self.nml`, not `self.nmls`."""
+    from pifuhd_amd import _lib
+    gold = np.load(os.path.join(golden_dir, 'coarse_api.npz'))
+    netG, netMR, *_ = _build(mlp_norm)
+    calib = calib_tensor()
+    pts = seeded_points(61, 200, lim=0.95)
+    assert netG.get_im_feat() is netG.im_feat_list[-1]
+    for pix in (_lib.PIX_OFF, _lib.PIX_ALWAYS):
+        _lib.call('pifu_set_pixel_tables', netG._ctx.h, pix)
+        for dtag, delta in (('d1', 0.1), ('d001', 0.001)):
+            netG.nmls = None
+            netG.calc_normal(pts, calib, delta=delta, keep_pred=True) if delta != 0.1 else netG.calc_normal(pts, calib, keep_pred=True)
+            assert netG.nmls is None and tuple(netG.nml.shape) == (1, 3, 200)
+            p4 = netG.nml_preds.reshape(-1).cpu().numpy()
+            e = float(np.abs(p4 - gold[f'{tag}_{dtag}_pred4']).max())
+            observed(f'coarse_calc_normal[{tag},{dtag},pix{pix}]', gpu_pred4=e)
+            assert e < TOL, (tag, dtag, pix, e)
+            w4 = gold[f'{tag}_{dtag}_pred4'].reshape(-1, 4)
+            strong = np.abs(w4[:, 1:] - w4[:, :1]).max(1) > 1e-3
+            assert np.abs(netG.nml[0].cpu().numpy()[:, strong] - gold[f'{tag}_{dtag}_nml'][:, strong]).max() < 5e-2
+    _lib.call('pifu_set_pixel_tables', netG._ctx.h, _lib.PIX_AUTO)
+    q = seeded_points(62, 600, lim=1.1)
+    g = torch.Generator().manual_seed(6200)
+    labels = (torch.rand(1, 1, 600, generator=g) > 0.5).float()
+    netG.query(q, calib, labels=labels)
+    assert float(netG.labels.sum().item()) == float(gold[f'{tag}_labels_masked_sum'][0])
+    err = netG.get_error(0.7)
+    want = float(gold[f'{tag}_err_occ'][0])
+    assert set(err) == {'Err(occ)'} and abs(float(err['Err(occ)']) - want) < 1e-4 * max(1.0, want)
+    with pytest.raises(RuntimeError):
+        netG.calc_normal(pts[:, :, :0], calib)
+    with pytest.raises(AttributeError):
+        from pifuhd_amd.nets import BasePIFuNet
+        BasePIFuNet().get_error()
