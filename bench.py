@@ -117,6 +117,91 @@ def smoother_subject(args, dev, data):
     return netMR2
 
 
+def gen_mesh_on_roofline(recon, _lib, netMR, dev, data, res, runs, td, tag, log, cold=None):
+    """`runs` timed gen_mesh calls of one subject at `res`^3 after a warm-up call at that size (arenas, pinned result slabs,
+    pixel table), the median run's phases, and the call on the roofline: ALGORITHMIC FLOPs executed by one call (MLP GEMM
+    launches + encoder convolutions, counted by the library) / wall time / the fp32-matrix peak, the GEMMs' busy time, and -
+    from one more, untimed call whose phase boundaries synchronise - the split into reconstruction / normals / encoders."""
+    import torch
+    h = netMR._ctx.h
+
+    def drop(name):
+        for f in (name, name[:-4] + '.png'):
+            try:
+                os.remove(os.path.join(td, f))
+            except OSError:
+                pass
+    torch.cuda.synchronize(dev)
+    w0 = time.perf_counter()
+    recon.gen_mesh(res, netMR, dev, data, os.path.join(td, tag + '_warm.obj'))
+    torch.cuda.synchronize(dev)
+    drop(tag + '_warm.obj')
+    first_call = round(time.perf_counter() - w0, 4)
+    if cold is not None:
+        cold['first_gen_mesh_call_s'] = first_call
+    reset_prof(_lib, h)
+    _lib.call('pifu_profile_enable', h, 1)
+    try:
+        run_t = []
+        for k in range(max(runs, 1)):      # distinct files: replacing a 470 MB file costs its page frees
+            tk = {}
+            recon.gen_mesh(res, netMR, dev, data, os.path.join(td, '%s_%d.obj' % (tag, k)), timings=tk)
+            run_t.append(tk)
+            drop('%s_%d.obj' % (tag, k))
+        _lib.call('pifu_profile_enable', h, 0)
+        extra = {'mc': read_prof(_lib, h, _lib.PROF_MC, 0), 'mc_nodes': read_prof(_lib, h, _lib.PROF_MC_NODES, 0)}
+        gm_ms, gm_n, gm_fl = read_prof(_lib, h, _lib.PROF_GEMM)          # the MLP GEMM launches of the timed runs
+        _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)               # the encoders' convolutions (counted, not timed)
+        nr = len(run_t)
+        gm_ms, gm_n, gm_fl, en_n, en_fl = gm_ms / nr, gm_n // nr, gm_fl / nr, en_n // nr, en_fl / nr
+        timings = sorted(run_t, key=lambda t: t['total_s'])[nr // 2]      # the median run, phase by phase
+        res_d = {'resolution': res, 'use_octree': True,
+                 **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
+                 'total_s_is': 'median of the runs below (each a complete gen_mesh call incl. both encoders, PNG and OBJ)',
+                 'runs_total_s': [round(t['total_s'], 4) for t in run_t], 'first_call_s': first_call}
+        tot = timings['total_s']
+        ro = {'bound': 'mfma', 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+              'executed_tflop_per_call': round((gm_fl + en_fl) / 1e12, 3),
+              'mlp_gemm_tflop_per_call': round(gm_fl / 1e12, 3), 'mlp_gemm_launches_per_call': gm_n,
+              'encoder_conv_tflop_per_call': round(en_fl / 1e12, 3), 'encoder_conv_launches_per_call': en_n,
+              'achieved': round((gm_fl + en_fl) / tot / 1e12, 2),
+              'frac': round((gm_fl + en_fl) / tot / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+              'mlp_gemm_busy_s_per_call': round(gm_ms * 1e-3, 4),
+              'mlp_gemm_busy_share_of_call': round(gm_ms * 1e-3 / tot, 4),
+              'mlp_gemm_frac_while_busy': round(gm_fl / (gm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if gm_ms > 0 else None,
+              'definition': 'ALGORITHMIC FLOPs executed by one gen_mesh call (k_mlp_gemm_tri launches: 2 * valid points * Cout '
+                            '* Cin; encoder convolutions: 2 * output pixels * Cout * Cin * taps) / total_s / peak; busy = summed '
+                            'HIP-event durations of the GEMM launches'}
+        try:
+            reset_prof(_lib, h)
+            _lib.call('pifu_profile_enable', h, 1)
+            tp = {'profile_phases': True}
+            recon.gen_mesh(res, netMR, dev, data, os.path.join(td, tag + '_phases.obj'), timings=tp)
+            _lib.call('pifu_profile_enable', h, 0)
+            drop(tag + '_phases.obj')
+            for ph in ('reconstruction', 'normals'):
+                fl, ms, sec = tp['gemm_flop_' + ph], tp['gemm_ms_' + ph], timings[ph + '_s']
+                ro[ph] = {'mlp_gemm_tflop': round(fl / 1e12, 3), 'phase_s': round(sec, 4), 'mlp_gemm_busy_s': round(ms * 1e-3, 4),
+                          'frac': round(fl / sec / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                          'frac_while_busy': round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if ms > 0 else None}
+            ro['encoders'] = {'conv_tflop': round(en_fl / 1e12, 3), 'phase_s': round(timings['filter_s'], 4),
+                              'frac': round(en_fl / timings['filter_s'] / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4)}
+        except Exception as e:
+            ro['phase_split_error'] = repr(e)
+        res_d['roofline'] = ro
+        log(f"gen_mesh[{tag}] {res}^3: {tot:.4f} s, {timings.get('n_verts')} vertices; roofline {ro['executed_tflop_per_call']} TFLOP "
+            f"= {ro['achieved']} TFLOP/s = {ro['frac']} of peak")
+        return res_d, timings, extra, nr
+    finally:
+        _lib.call('pifu_profile_enable', h, 0)
+
+
+def octree_share(mesh_util, netMR, calib, res):
+    """Points the octree of `reconstruction()` evaluates on this subject, and their share of the res^3 grid."""
+    _, n_eval = mesh_util.eval_grid_device(netMR, calib, res, 5000, True)
+    return {'points_evaluated': int(n_eval), 'share_of_grid': round(n_eval / float(res) ** 3, 4)}
+
+
 def mesh_digest(verts, faces, color):
     """56 bits of the sha256 over a mesh's arrays, as a non-negative int64 (for an all-reduce across ranks)."""
     import hashlib
@@ -190,7 +275,23 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
     # gets its share of the cores, not all of them; where only rank 0 writes (the sharded legs) it may use the machine
     host_threads = max(2, (os.cpu_count() or 8) // max(world, 1))
     res['host_threads_per_rank_independent_subjects'] = host_threads
-    extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds')
+    extra = ('collectives', 'collective_bytes', 'collective_s', 'collective_host_s', 'colour_rounds', 'replicated_s', 'replicated_host_s')
+
+    def fixed_cost(t, total_s, coll_max):
+        """What of a sharded call does NOT shrink with the number of ranks, from the call's own measurements (rank 0's view):
+        the dealt-out encoder chain (netF -> fine hourglass stays on the critical path), the work every rank repeats on the
+        replicated field (octree bookkeeping, marching cubes below the slab threshold), the time inside the collectives
+        (max over ranks: it includes waiting for the slowest rank), the PNG hand-off and the tail after the GPU phase (last
+        colour round's host copy + vertex lines).  total = fixed + shrinking; with twice the ranks the shrinking part halves
+        at best - so a curve that flattens can be read off the line that shows it."""
+        parts = {'encoder_chain_s': t.get('filter_s', 0.0), 'replicated_s': t.get('replicated_s', 0.0) or 0.0,
+                 'collective_s': coll_max, 'png_s': t.get('png_s', 0.0), 'obj_tail_s': t.get('obj_s', 0.0)}
+        fixed = float(sum(parts.values()))
+        shrinking = max(total_s - fixed, 0.0)
+        return {'predicted_fixed_s': round(fixed, 4), 'predicted_fixed_parts': {k: round(float(v), 5) for k, v in parts.items()},
+                'shrinking_s': round(shrinking, 4), 'fixed_share_of_total': round(fixed / total_s, 4) if total_s > 0 else None,
+                'projected_total_s_at_twice_the_ranks': round(fixed + shrinking / 2.0, 4),
+                'speedup_ceiling_vs_this_run': round(total_s / fixed, 2) if fixed > 0 else None}
 
     with tempfile.TemporaryDirectory() as td:
         scratch.append(td)
@@ -225,7 +326,8 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                                           # level + one of the colours per round + the four broadcasts of the dealt-out encoders;
                                           # the time between the events around them includes waiting for the slowest rank; its
                                           # max over ranks beside it
-                                          **{k: timings.get(k) for k in extra}, 'collective_s_max_over_ranks': round(red[-1], 5)}
+                                          **{k: timings.get(k) for k in extra}, 'collective_s_max_over_ranks': round(red[-1], 5),
+                                          **fixed_cost(timings, red[0], red[-1])}
             log(f"gen_mesh sharded: {red[0]:.3f} s")
         else:
             res['one_subject_sharded'] = {'error': err or 'failed on another rank'}
@@ -304,7 +406,8 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                     'n_faces': timings.get('n_faces'), 'result_on': 'all', **{k: timings.get(k) for k in extra},
                     'marching_cubes': 'one axis-0 slab per rank' if args.config5_res >= pdist.SLAB_MC_MIN_RESOLUTION
                     else 'replicated (below dist.SLAB_MC_MIN_RESOLUTION)',
-                    'mesh_identical_on_all_ranks': bool(int(t[0]) == -int(t[1])), 'mesh_sha256_56bit': '%014x' % int(t[0])}
+                    'mesh_identical_on_all_ranks': bool(int(t[0]) == -int(t[1])), 'mesh_sha256_56bit': '%014x' % int(t[0]),
+                    **fixed_cost(timings, red[0], float(timings.get('collective_s', 0.0) or 0.0))}
                 log(f"config 5: gen_mesh {args.config5_res}^3 sharded over {world} ranks: {red[0]:.3f} s, {timings.get('n_verts')} vertices")
             else:
                 res['config5_1024'] = {'error': err or 'failed on another rank'}
@@ -323,6 +426,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time bound of the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-alt', action='store_true', help='skip the second CPU baseline run on all host threads')
     ap.add_argument('--no-genmesh', action='store_true')
     ap.add_argument('--no-lean-pass', action='store_true', help='skip the extra pass without the unread coarse tail')
     ap.add_argument('--dist-selftest', action='store_true',
@@ -398,6 +502,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=20))
         if args.dist_selftest:
             pdist.ALWAYS_COLLECTIVE = True
+        if args.dist_selftest or one_gpu_test:
+            pdist.SHARDED_MIN_RESOLUTION = 0          # functional runs use small grids: they are to exchange, not to fall under the size guard
 
     # ---- model + inputs (outside the timed region) ---------------------------------------------------
     oc = config.coarse_opt(in_image_channels=args.image_channels)
@@ -440,7 +546,11 @@ def main():
     if args.no_depth_walk:
         flags |= _lib.Q_NO_DEPTH_WALK
     h = netMR._ctx.h
-    _lib.call('pifu_reserve', h, args.batch_rows)
+    # the batch workspace sized from what the device has free: the whole of --batch-rows on a GPU of its own (26 GB of 288),
+    # a share of the card when ranks share it (PIFU_BENCH_ONE_GPU) - N contexts per device never run it out of memory
+    rows_fit = C.c_int64(0)
+    _lib.call('pifu_reserve_auto', h, args.batch_rows, 0.5 / (world if one_gpu_test else 1), C.byref(rows_fit))
+    batch_rows = int(rows_fit.value)
 
     def step():
         return pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, flags)
@@ -524,7 +634,7 @@ def main():
             'workload': f'dense {res[0]}x{res[1]}x{res[2]} lattice ({R}^3 per GPU, axis-0 chunk-range slabs, RCCL '
                         f'all-gather of the fp32 field), coarse+fine PIFuMRNet query, chunk {args.chunk}, '
                         f'1024px {"RGB-D (6-channel)" if args.image_channels == 6 else "RGB"} image + 512px, name-seeded weights',
-            'queries_per_step': total, 'chunk': args.chunk, 'batch_rows': args.batch_rows, 'coarse_tail': 'skipped' if args.lean else 'computed',
+            'queries_per_step': total, 'chunk': args.chunk, 'batch_rows': batch_rows, 'batch_rows_requested': args.batch_rows, 'coarse_tail': 'skipped' if args.lean else 'computed',
             'column_sharing': not args.no_column_sharing,
             'depth_walk': not (args.no_depth_walk or args.no_column_sharing),
             'flop_per_query_canonical': FLOP_PER_QUERY,
@@ -792,27 +902,29 @@ def main():
         # of this oracle is >10x slower than a 32-thread one), so the baseline uses at most 32 threads and
         # says so in `cores`; the sample is bounded by wall time (~args.cpu_seconds), not by a chunk count.
         ncores = min(os.cpu_count() or 1, args.cpu_threads)
-        torch.set_num_threads(ncores)
         ref = O.OracleNets(sd, oc, of, fine_training=True)
         ref.feat_coarse = netG.im_feat_list[-1].cpu()
         ref.feat_fine = netMR.im_feat_list[-1].cpu()
         calib_inv = np.linalg.inv(calib[0].numpy().astype(np.float64))
         first = (total // 2 // args.chunk) * args.chunk            # a slab from the middle of the grid
-        want = []
-        npts = 0
-        cpu_s = 0.0
-        with torch.no_grad():
-            while npts < args.cpu_chunks * args.chunk and first + npts < total:
-                n_c = min(args.chunk, total - first - npts)
-                flat = np.arange(first + npts, first + npts + n_c, dtype=np.int64)
-                pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
-                c0 = time.perf_counter()
-                want.append(ref.query(pts, calib)[0, 0])
-                cpu_s += time.perf_counter() - c0
-                npts += n_c
-                if cpu_s > args.cpu_seconds and npts >= 2 * args.chunk:
-                    break
-        want = torch.cat(want).numpy()
+
+        def time_oracle(nthreads, max_chunks, seconds):
+            """The same chunks of the lattice, from `first` on, through the oracle on `nthreads` torch threads."""
+            torch.set_num_threads(nthreads)
+            vals, npts, cpu_s = [], 0, 0.0
+            with torch.no_grad():
+                while npts < max_chunks * args.chunk and first + npts < total:
+                    n_c = min(args.chunk, total - first - npts)
+                    flat = np.arange(first + npts, first + npts + n_c, dtype=np.int64)
+                    pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
+                    c0 = time.perf_counter()
+                    vals.append(ref.query(pts, calib)[0, 0])
+                    cpu_s += time.perf_counter() - c0
+                    npts += n_c
+                    if cpu_s > seconds and npts >= 2 * args.chunk:
+                        break
+            return torch.cat(vals).numpy(), npts, cpu_s
+        want, npts, cpu_s = time_oracle(ncores, args.cpu_chunks, args.cpu_seconds)
         log(f'cpu baseline done: {npts} queries in {cpu_s:.1f} s on {ncores} threads')
         got = field[first:first + npts].cpu().numpy()
         out['cpu_baseline'] = {
@@ -821,6 +933,17 @@ def main():
                                       f'the same lattice, torch-CPU oracle (oracle/pifu_oracle.py), {cpu_s:.1f} s, '
                                       f'{ncores} of {os.cpu_count()} host threads',
         }
+        # the same sample (at most the same chunks, at most the same wall time) on EVERY hardware thread of the host: the
+        # reader can check on this machine that the bounded thread count above is the faster choice for 5 000-point GEMMs
+        all_cores = os.cpu_count() or 1
+        if all_cores != ncores and not args.no_cpu_alt:
+            _, npts_alt, cpu_s_alt = time_oracle(all_cores, npts // args.chunk, args.cpu_seconds)
+            torch.set_num_threads(ncores)
+            out['cpu_baseline'].update({
+                'cores_alt': all_cores, 'value_alt': round(npts_alt / cpu_s_alt / 1e6, 4),
+                'sample_alt': f'{npts_alt} queries of the same sample in {cpu_s_alt:.1f} s on all {all_cores} host threads',
+                'faster_choice': 'cores' if npts / cpu_s >= npts_alt / cpu_s_alt else 'cores_alt'})
+            log(f'cpu baseline on all {all_cores} threads: {npts_alt} queries in {cpu_s_alt:.1f} s')
         out['parity_check_max_abs_diff'] = float(np.abs(got - want).max())
         for key, fld in split_fields.items():      # the opt-in arithmetics against the same oracle sample
             out[key]['max_abs_diff_vs_cpu_oracle'] = float(np.abs(fld[first:first + npts].cpu().numpy() - want).max())
@@ -837,72 +960,14 @@ def main():
                 except OSError:
                     pass
             try:
-                # warm-up at the timed size: the marching-cubes arena, the octree state and the pinned result buffers of a
-                # 512^3 mesh are allocated here, as they are for every subject after the first one of a recon() loop
-                torch.cuda.synchronize(dev)
-                w0 = time.perf_counter()
-                recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'warm.obj'))
-                torch.cuda.synchronize(dev)
-                drop('warm.obj')
-                cold['first_gen_mesh_call_s'] = round(time.perf_counter() - w0, 4)
-                log(f"gen_mesh warm-up done (first call at this size: {cold['first_gen_mesh_call_s']} s)")
-                reset_prof(_lib, h)
-                _lib.call('pifu_profile_enable', h, 1)
-                runs = []
-                for k in range(max(args.genmesh_runs, 1)):      # distinct files: replacing a 470 MB file costs its page frees
-                    tk = {}
-                    recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'mesh%d.obj' % k), timings=tk)
-                    runs.append(tk)
-                    os.remove(os.path.join(td, 'mesh%d.obj' % k))
-                _lib.call('pifu_profile_enable', h, 0)
-                mc_ms, mc_n, mc_bytes = read_prof(_lib, h, _lib.PROF_MC)
-                mc_ms, mc_bytes = mc_ms / len(runs), mc_bytes / len(runs)
-                nd_ms, nd_n, nd_bytes = read_prof(_lib, h, _lib.PROF_MC_NODES)
+                gm, timings, extra, nruns = gen_mesh_on_roofline(recon, _lib, netMR, dev, data, args.genmesh_res, args.genmesh_runs, td,
+                                                                 'headline', log, cold)
+                out['gen_mesh'] = gm
+                out['gen_mesh'].update(octree_share(mesh_util, netMR, calib, args.genmesh_res))
+                mc_ms, mc_n, mc_bytes = extra['mc']
+                mc_ms, mc_bytes = mc_ms / nruns, mc_bytes / nruns
+                nd_ms, nd_n, nd_bytes = extra['mc_nodes']
                 nd_ms, nd_bytes = nd_ms / max(nd_n, 1), nd_bytes / max(nd_n, 1)
-                gm_ms, gm_n, gm_fl = read_prof(_lib, h, _lib.PROF_GEMM)          # the MLP GEMM launches of the timed runs
-                _, en_n, en_fl = read_prof(_lib, h, _lib.PROF_ENC)               # the encoders' convolutions (counted, not timed)
-                gm_ms, gm_n, gm_fl, en_n, en_fl = gm_ms / len(runs), gm_n // len(runs), gm_fl / len(runs), en_n // len(runs), en_fl / len(runs)
-                timings = sorted(runs, key=lambda t: t['total_s'])[len(runs) // 2]      # the median run, phase by phase
-                out['gen_mesh'] = {'resolution': args.genmesh_res, 'use_octree': True,
-                                   **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
-                                   'total_s_is': 'median of the runs below (each a complete gen_mesh call incl. both encoders, '
-                                                 'PNG and OBJ)', 'runs_total_s': [round(t['total_s'], 4) for t in runs],
-                                   'first_call_s': cold.get('first_gen_mesh_call_s')}
-                # M2 on the roofline (BASELINE.json: 'absolute and as fraction of the HBM/MFMA roofline'): the call is bound by
-                # the fp32 matrix pipe - MLP GEMMs of the octree levels and of the colour loop + the encoders' convolutions;
-                # frac = executed algorithmic FLOPs of ONE call / its wall time / the 157.3 TFLOP/s fp32-matrix peak.  One more
-                # (untimed: each read synchronises) call splits the GEMM work by phase.
-                tot = timings['total_s']
-                ro = {'bound': 'mfma', 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                      'executed_tflop_per_call': round((gm_fl + en_fl) / 1e12, 3),
-                      'mlp_gemm_tflop_per_call': round(gm_fl / 1e12, 3), 'mlp_gemm_launches_per_call': gm_n,
-                      'encoder_conv_tflop_per_call': round(en_fl / 1e12, 3), 'encoder_conv_launches_per_call': en_n,
-                      'achieved': round((gm_fl + en_fl) / tot / 1e12, 2),
-                      'frac': round((gm_fl + en_fl) / tot / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
-                      'mlp_gemm_busy_s_per_call': round(gm_ms * 1e-3, 4),
-                      'mlp_gemm_busy_share_of_call': round(gm_ms * 1e-3 / tot, 4),
-                      'mlp_gemm_frac_while_busy': round(gm_fl / (gm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if gm_ms > 0 else None,
-                      'definition': 'ALGORITHMIC FLOPs executed by one gen_mesh call (k_mlp_gemm_tri launches: 2 * valid points * Cout '
-                                    '* Cin; encoder convolutions: 2 * output pixels * Cout * Cin * taps) / total_s / peak; busy = summed '
-                                    'HIP-event durations of the GEMM launches'}
-                try:
-                    reset_prof(_lib, h)
-                    _lib.call('pifu_profile_enable', h, 1)
-                    tp = {'profile_phases': True}
-                    recon.gen_mesh(args.genmesh_res, netMR, dev, data, os.path.join(td, 'phases.obj'), timings=tp)
-                    _lib.call('pifu_profile_enable', h, 0)
-                    os.remove(os.path.join(td, 'phases.obj'))
-                    for ph in ('reconstruction', 'normals'):
-                        fl, ms, sec = tp['gemm_flop_' + ph], tp['gemm_ms_' + ph], timings[ph + '_s']
-                        ro[ph] = {'mlp_gemm_tflop': round(fl / 1e12, 3), 'phase_s': round(sec, 4), 'mlp_gemm_busy_s': round(ms * 1e-3, 4),
-                                  'frac': round(fl / sec / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
-                                  'frac_while_busy': round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4) if ms > 0 else None}
-                    ro['encoders'] = {'conv_tflop': round(en_fl / 1e12, 3), 'phase_s': round(timings['filter_s'], 4),
-                                      'frac': round(en_fl / timings['filter_s'] / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4)}
-                except Exception as e:
-                    ro['phase_split_error'] = repr(e)
-                out['gen_mesh']['roofline'] = ro
-                log(f"gen_mesh roofline: {ro['executed_tflop_per_call']} TFLOP in {tot:.3f} s = {ro['achieved']} TFLOP/s = {ro['frac']} of peak")
                 if mc_ms > 0:
                     ach = mc_bytes / (mc_ms * 1e-3) / 1e9
                     secondary.append({

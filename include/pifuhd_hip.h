@@ -105,7 +105,8 @@ enum {
  *      a context is still used by ONE call at a time, but consecutive calls may be enqueued on different streams without the
  *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call.
  *   5: round 6 - pifu_enc_set_param_device BORROWS the caller's tensor (no copy, no synchronisation; it must outlive the
- *      registration); pifu_calc_normal_coarse, pifu_reserve_auto and PIFU_Q_NO_COARSE_MASK added; the library exports nothing
+ *      registration); pifu_calc_normal_coarse, pifu_reserve_auto, pifu_effective_chunk and PIFU_Q_NO_COARSE_MASK added; calls of more than
+ *      `chunk` points are regrouped when every MLP norm is pointwise (see pifu_effective_chunk); the library exports nothing
  *      but the PIFU_API entry points of this header (-fvisibility=hidden + export map). */
 #define PIFU_ABI_VERSION 5
 PIFU_API const char *pifu_last_error(void);
@@ -217,6 +218,20 @@ PIFU_API int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, in
  * pred_coarse [n] = netG.preds[0][0], phi [Cphi][n] = netG.phi[0] (only when n <= chunk). */
 PIFU_API int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const float *calib, int64_t chunk,
                int flags, float *pred_fine, float *pred_coarse, float *phi, pifu_stream stream);
+
+/* Pointwise MLP norms (PIFU_NORM_NONE - the published pifuhd.pt - or PIFU_NORM_BATCH_EVAL, at every level the call runs): a
+ * point's result does not depend on the query() call it is evaluated in, so `chunk` only says how the reference would CUT the
+ * work, and the library regroups it: lattice calls (pifu_eval_lattice, pifu_eval_grid) always, point lists (pifu_query,
+ * pifu_calc_normal_chunked) when they span more than one chunk.  Groups of PIFU_POINTWISE_CHUNK rows - for a dense lattice
+ * range the nearest multiple of lcm(128, res[2]), i.e. whole GEMM tiles and whole lattice columns - with no padding rows, no
+ * statistics passes, and depth-walk segments that are complete columns.  Same numbers as the reference's cut up to fp32
+ * summation order (the depth walk restarts at group boundaries).  The grouping of a lattice call is a function of
+ * (chunk, res[2], the norms) alone and is cut relative to `first`; pifu_effective_chunk returns it (`chunk` itself when a norm
+ * couples the chunk), so that a sharded caller deals out whole groups and N ranks reproduce one rank's field bit for bit
+ * (rgb-d-pifuhd_amd/dist.py).  res2 = res[2] for a dense lattice range (index == NULL), 0 for an index list; of `flags` only
+ * PIFU_Q_COARSE_ONLY matters. */
+#define PIFU_POINTWISE_CHUNK 16384
+PIFU_API int64_t pifu_effective_chunk(pifu_ctx *ctx, int64_t chunk, int res2, int flags);
 
 /* ---- lattice evaluation: create_grid + calib^-1 + eval_func (mesh_util.py:12-38,59-74) -------- */
 /* Evaluates `count` points of the C-ordered lattice res[0] x res[1] x res[2] over [-1,1)^3

@@ -19,6 +19,7 @@ PROF_GEMM, PROF_SAMPLER, PROF_MC, PROF_ENC, PROF_MC_NODES, PROF_WALK, PROF_ENC_C
 Q_COARSE_ONLY, Q_NO_FINE_MASK, Q_FULL_COARSE, Q_NO_COLUMN_SHARING, Q_NO_DEPTH_WALK, Q_NO_COARSE_MASK = 1, 2, 4, 8, 16, 32
 ENC_ALL_STACKS, ENC_DEFER_JOIN, ENC_NORMALS_ONLY, ENC_NORMALS_GIVEN, ENC_NO_WINOGRAD = 1, 2, 4, 8, 16
 PIX_OFF, PIX_AUTO, PIX_ALWAYS = 0, 1, 2          # pifu_set_pixel_tables
+POINTWISE_CHUNK = 16384                   # PIFU_POINTWISE_CHUNK
 PIXEL_TABLE_MIN_POINTS = 16384            # the automatic threshold: max(this, H * W of the coarse map) points per call
 ARENA_QUERY, ARENA_MC, ARENA_OCTREE, ARENA_COLUMN, ARENA_PIXEL, ARENA_MISC = 0, 1, 2, 3, 4, 5
 COMM_ID_BYTES = 128
@@ -66,6 +67,7 @@ SIGNATURES = {
     'pifu_filter_coarse': (_i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     'pifu_filter_fine': (_i32, [_p, _p, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'pifu_query': (_i32, [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
+    'pifu_effective_chunk': (_i64, [_p, _i64, _i32, _i32]),
     'pifu_eval_lattice': (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _p]),
     'pifu_octree_begin': (_i32, [_p, _i32, _p, _p, _p]),
     'pifu_octree_select': (_i32, [_p, _i32, _i32, _p, _p, _i64, C.POINTER(_i64), _p]),

@@ -1772,9 +1772,10 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 hipLaunchKernelGGL(k_expand_pix, dim3(ntm, pa.n0 + px->nS), dim3(256), 0, st, pa);
             } else if (ns == 0) {   // coarse layer 0: no per-point product left
                 // with the depth walk nobody reads this layer's output: statistics only
+                if (walk && !stats) continue;      // pointwise norm + depth walk: neither the output nor statistics are needed
                 hipLaunchKernelGGL(k_expand, dim3(ntm, l.cout_pad / 128), dim3(256), 0, st, (const float *)T.Q[L], T.ldq[L],
                                    (const float *)l.wz, (const float *)l.bias, (const float *)pl.zf, (const int *)pl.colidx,
-                                   (walk && stats) ? (float *)nullptr : b.out[i], l.cout_pad, stats ? b.partial[i] : nullptr, g);
+                                   walk ? (float *)nullptr : b.out[i], l.cout_pad, stats ? b.partial[i] : nullptr, g);
             } else if (walk && i == 1) {
                 const MlpLayer &l0 = m.layer[0];
                 const WalkPlan &w = pl.wk;
@@ -1876,6 +1877,37 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
     return PIFU_OK;
 }
 
+// Pointwise MLP norms - none at all (MLP.py:37-41,65-69: what the published pifuhd.pt uses) or BatchNorm1d on running
+// statistics - make a point's result independent of the query() call it is evaluated in: the reference's chunk size
+// (num_samples) then only decides how the work is CUT, and the library cuts it its own way: whole 128-row tiles (no
+// padding rows: 5 000 -> 5 120 costs 2.4 %), for dense lattices whole columns too (every depth-walk segment is then a
+// complete column), no statistics epilogue / k_norm_finalize launches.  The grouping depends on (chunk, n, res[2]) only -
+// never on the batch, the rank or the number of points - and the sharded evaluation deals out whole groups
+// (pifu_effective_chunk), so N ranks reproduce one rank's field bit for bit.
+static inline bool norm_pointwise(const Mlp &m) { return m.norm == PIFU_NORM_NONE || m.norm == PIFU_NORM_BATCH_EVAL; }
+
+static int64_t effective_chunk(const pifu_ctx *ctx, int64_t chunk, int64_t n, int res2, bool fine, bool lattice)
+{
+    const bool pointwise = norm_pointwise(ctx->mlp[0]) && (!fine || norm_pointwise(ctx->mlp[1]));
+    // lattice sources are always regrouped (the grouping must not depend on how many points a rank's share holds); explicit
+    // point lists only when they span several chunks (a single-chunk pifu_query may export phi)
+    if (!pointwise || (!lattice && n <= chunk)) return chunk;
+    int64_t unit = BM;
+    if (res2 > 0) {         // lcm(128, res2): whole tiles and whole columns
+        int64_t a = BM, b = res2;
+        while (b) { const int64_t t = a % b; a = b; b = t; }
+        unit = (int64_t)BM / a * res2;
+    }
+    int64_t k = (PIFU_POINTWISE_CHUNK + unit / 2) / unit;
+    return unit * (k < 1 ? 1 : k);
+}
+
+int64_t pifu_effective_chunk(pifu_ctx *ctx, int64_t chunk, int res2, int flags)
+{
+    if (!ctx || chunk <= 0) return chunk;
+    return effective_chunk(ctx, chunk, 0, res2, !(flags & PIFU_Q_COARSE_ONLY), true);
+}
+
 int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n, const int32_t *res,
                     const double *calib_inv, const int64_t *index, int64_t first, const float *calib,
                     int64_t chunk, int flags, float *pred_fine, float *pred_coarse, float *phi,
@@ -1907,6 +1939,8 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                      ctx->feat[1].C, mc.dims[mc.merge_layer + 1]);
     PIFU_HIP(hipSetDevice(ctx->device));
 
+    // (the phi export belongs to single-chunk calls, which are never regrouped)
+    chunk = effective_chunk(ctx, chunk, n, src_mode == 1 ? res[2] : 0, fine, src_mode == 1 || src_mode == 2);
     const int64_t eff_chunk = chunk < n ? chunk : n;
     const int64_t P = round_up(eff_chunk, BM);
     PIFU_REQUIRE(P <= (int64_t)1 << 30, PIFU_ERR_NOMEM, "chunk of %lld points is too large", (long long)eff_chunk);

@@ -130,7 +130,8 @@ def sharded_eval(total_points: int, chunk: int, eval_fn, device, group=None):
 
     eval_fn(first, count) -> float32 tensor [count] on `device` (predictions of list entries
     first .. first+count, chunks cut relative to `first`).  Returns the float32 tensor [total_points],
-    identical on every rank."""
+    identical on every rank.  `chunk` is the granularity of the deal: the reference's query() chunk when the MLP's norm
+    couples it, the library's own grouping (`effective_chunk`) when every norm is pointwise."""
     import torch.distributed as dist
     rank, ws = world()
     if not collective_active():
@@ -143,6 +144,15 @@ def sharded_eval(total_points: int, chunk: int, eval_fn, device, group=None):
     full = torch.empty(ws * slot, device=device, dtype=torch.float32)
     _timed(lambda: _all_gather(full, local, group), full.numel() * 4, device)
     return full[:total_points]
+
+
+def effective_chunk(ctx, chunk, res2=0, flags=0):
+    """The granularity at which a lattice evaluation may be dealt out without changing a single bit (`pifu_effective_chunk`):
+    the reference's query() chunk while a norm of the MLPs couples the points of a call (GroupNorm, train-mode BatchNorm);
+    with pointwise norms - the published pifuhd.pt has none - the library's own grouping: 16 384 rows, for a dense lattice
+    whole columns, i.e. raw Z-slabs of the voxel grid with no padding to 5 000-point chunks."""
+    from . import _lib
+    return int(_lib.load().pifu_effective_chunk(ctx.h, int(chunk), int(res2), int(flags)))
 
 
 def eval_lattice_sharded(net, calib_tensor, res, chunk, flags=0, group=None):
@@ -162,7 +172,7 @@ def eval_lattice_sharded(net, calib_tensor, res, chunk, flags=0, group=None):
         _lib.call('pifu_eval_lattice', ctx.h, res_a, calib_inv.ctypes.data_as(C.c_void_p),
                   calib.ctypes.data_as(C.c_void_p), None, first, count, int(chunk), flags, _ptr(out), _stream_ptr(dev))
         return out
-    return sharded_eval(total, int(chunk), eval_fn, dev, group)
+    return sharded_eval(total, effective_chunk(ctx, chunk, int(res[2]), flags), eval_fn, dev, group)
 
 
 def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, threshold=0.05, flags=0, group=None):
@@ -185,22 +195,22 @@ def eval_grid_octree_sharded(net, calib_tensor, R, chunk, init_resolution=64, th
     evaluated = 0
     while reso > 0:
         cnt = C.c_int64(0)
-        _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st)
+        replicated(lambda: _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), None, 0, C.byref(cnt), st), dev)
         n = cnt.value
         idx = torch.empty(max(n, 1), device=dev, dtype=torch.int64)
         vals = None
         if n:
-            _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st)
+            replicated(lambda: _lib.call('pifu_octree_select', ctx.h, R, reso, _ptr(notproc), _ptr(idx), n, C.byref(cnt), st), dev)
 
             def eval_fn(first, count):
                 out = torch.empty(count, device=dev, dtype=torch.float32)
                 _lib.call('pifu_eval_lattice', ctx.h, res_a, calib_inv.ctypes.data_as(C.c_void_p),
                           calib.ctypes.data_as(C.c_void_p), _ptr(idx), first, count, int(chunk), flags, _ptr(out), st)
                 return out
-            vals = sharded_eval(n, int(chunk), eval_fn, dev, group).contiguous()
+            vals = sharded_eval(n, effective_chunk(ctx, chunk, 0, flags), eval_fn, dev, group).contiguous()
             evaluated += n
-        _lib.call('pifu_octree_commit', ctx.h, R, reso, float(threshold), _ptr(idx), _ptr(vals), n, _ptr(sdf),
-                  _ptr(notproc), st)
+        replicated(lambda: _lib.call('pifu_octree_commit', ctx.h, R, reso, float(threshold), _ptr(idx), _ptr(vals), n, _ptr(sdf),
+                                     _ptr(notproc), st), dev)
         if reso <= 1:
             break
         reso //= 2
@@ -250,9 +260,10 @@ _stats = None
 
 def stats_begin():
     """Start recording: every collective of the sharded entry points is bracketed by events on the stream it is issued
-    from and its gathered bytes are counted, until `stats_end()`."""
+    from and its gathered bytes are counted, until `stats_end()`; so is the work every rank repeats on the replicated field
+    (`replicated()`: octree bookkeeping, marching cubes below the slab threshold) - what does not shrink with N."""
     global _stats
-    _stats = {'events': [], 'bytes': 0, 'calls': 0, 'host_s': 0.0}
+    _stats = {'events': [], 'bytes': 0, 'calls': 0, 'host_s': 0.0, 'rep_events': [], 'rep_host_s': 0.0}
 
 
 def stats_end():
@@ -267,8 +278,16 @@ def stats_end():
     for (e0, e1) in st['events']:
         e1.synchronize()
         ms += e0.elapsed_time(e1)
+    rep_ms = 0.0
+    for (e0, e1) in st['rep_events']:
+        e1.synchronize()
+        rep_ms += e0.elapsed_time(e1)
     return {'collectives': st['calls'], 'collective_bytes': st['bytes'], 'collective_s': round(ms * 1e-3, 5),
-            'collective_host_s': round(st['host_s'], 5)}
+            'collective_host_s': round(st['host_s'], 5),
+            # octree bookkeeping + (replicated) marching cubes of this rank: device time between the events around them, and
+            # the host time of those calls (the per-level count read-back waits for the level's evaluation, so the host
+            # figure includes it and is not additive)
+            'replicated_s': round(rep_ms * 1e-3, 5), 'replicated_host_s': round(st['rep_host_s'], 5)}
 
 
 def _timed(fn, nbytes, device):
@@ -288,6 +307,25 @@ def _timed(fn, nbytes, device):
         _stats['events'].append(ev)
     _stats['bytes'] += int(nbytes)
     _stats['calls'] += 1
+    return out
+
+
+def replicated(fn, device):
+    """Run `fn()` - work every rank repeats on the replicated field - and, while statistics are recorded, book the device time
+    between two events around it."""
+    import time
+    if _stats is None:
+        return fn()
+    dev = torch.device(device)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if dev.type == 'cuda' else None
+    if ev:
+        ev[0].record(torch.cuda.current_stream(dev))
+    h0 = time.perf_counter()
+    out = fn()
+    _stats['rep_host_s'] += time.perf_counter() - h0
+    if ev:
+        ev[1].record(torch.cuda.current_stream(dev))
+        _stats['rep_events'].append(ev)
     return out
 
 
@@ -346,6 +384,20 @@ def filter_sharded(net, coarse_image, fine_image, group=None):
 # `reconstruction(..., sharded=True)` runs marching cubes over one axis-0 slab per rank from this resolution on (below it
 # the replicated run is a few milliseconds and cheaper than the three exchanges of the slab form)
 SLAB_MC_MIN_RESOLUTION = 1024
+
+# Size guard of `gen_mesh(..., sharded=True)` / `reconstruction(..., sharded=True)`: below this grid resolution every rank
+# computes the whole call by itself (identical results on every rank, no collective).  A 64^3 call is ~15 ms of which the
+# encoders are most; its octree evaluates ~0.3 M points in 2 - 3 levels, and one exchange per level + one per colour round +
+# the four broadcasts of the dealt-out encoders (each a launch, a wait for the slowest rank and ~10 us of xGMI latency) cost
+# what they save.  From 128^3 on (0.055 s on one GPU, ~30 % of it the encoder chain) the sharded call is expected to win;
+# the threshold is a module variable so that a measured curve can move it.
+SHARDED_MIN_RESOLUTION = 128
+
+
+def sharded_call(resolution):
+    """True when a sharded entry point called at `resolution` exchanges data: more than one rank (or the single-rank
+    self-test) and a grid at or above the size guard."""
+    return collective_active() and int(resolution) >= SHARDED_MIN_RESOLUTION
 
 
 def marching_cubes_sharded(ctx, volume, level, group=None):

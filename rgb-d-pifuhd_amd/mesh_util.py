@@ -210,7 +210,8 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
     returns nothing): no host copies at all - `verts` and `faces` come back as None, the device vertices are still there."""
     ctx = _ctx_of(net)
     from . import dist as pdist
-    if sharded and pdist.collective_active():
+    sharded = sharded and pdist.sharded_call(resolution)      # below the size guard every rank computes the call alone
+    if sharded:
         flags = _lib.Q_COARSE_ONLY if isinstance(net, PIFuNetwNML) else 0
         R = int(resolution)
         if use_octree:
@@ -223,8 +224,10 @@ def reconstruction(net, cuda, calib_tensor, resolution, b_min, b_max, thresh=0.5
         # only what the reference's own try block can fail on - the level outside the volume's range (ValueError) or no
         # surface (RuntimeError), mesh_util.py:84,94-96 - is turned into the printed -1; anything else (an allocation, a
         # failed copy) surfaces as the error it is
-        if sharded and pdist.collective_active() and int(resolution) >= pdist.SLAB_MC_MIN_RESOLUTION:
+        if sharded and int(resolution) >= pdist.SLAB_MC_MIN_RESOLUTION:
             verts_d, faces_d = pdist.marching_cubes_sharded(ctx, sdf, thresh)
+        elif sharded:
+            verts_d, faces_d = pdist.replicated(lambda: marching_cubes_device(ctx, sdf, thresh), ctx.device)
         else:
             verts_d, faces_d = marching_cubes_device(ctx, sdf, thresh)
     except _lib.PifuError:               # (a RuntimeError too: a failed HIP call is not "no surface")

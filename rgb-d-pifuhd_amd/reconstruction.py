@@ -176,10 +176,13 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
     from . import dist as pdist
     dev = net.device
     rank, ws = pdist.world() if sharded else (0, 1)
-    exchange = sharded and pdist.collective_active()
+    in_group = sharded and pdist.collective_active()
+    # below dist.SHARDED_MIN_RESOLUTION (the size guard) every rank computes the whole call by itself - no collective, the
+    # same arrays everywhere; who writes the files and who returns the mesh stays as `result_on` says
+    exchange = in_group and pdist.sharded_call(res)
     if result_on not in ('rank0', 'all'):
         raise ValueError("result_on must be 'rank0' or 'all'")
-    wants_result = rank == 0 or result_on == 'all' or not exchange
+    wants_result = rank == 0 or result_on == 'all' or not in_group
     if exchange and timings is not None:
         pdist.stats_begin()
     # timings['profile_phases'] = True (bench.py, with pifu_profile_enable on): the executed GEMM FLOPs and the summed GEMM
@@ -270,7 +273,7 @@ def gen_mesh(res, net, cuda, data, save_path, thresh=0.5, use_octree=True, compo
                     color[L:R] = host_np[L:R]
 
         for (base, m) in rounds:
-            mine, (L, R), slot = pdist.round_rows(spans, base, m, wsx, rank, interval)
+            mine, (L, R), slot = pdist.round_rows(spans, base, m, wsx, rank if exchange else 0, interval)
             col_d = normals_of(*mine).contiguous() if mine is not None else None
             if exchange:
                 local = torch.zeros(slot, 3, device=dev, dtype=torch.float32)

@@ -224,9 +224,35 @@ def synthetic_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor
     return img.clamp_(-1.0, 1.0)
 
 
-def synthetic_inputs(load_size: int = 1024, channels: int = 3, seed: int = 0) -> dict:
-    """Data dict with the keys `gen_mesh` reads (`readData.py:106-116`, `reconstruction.py:29-34`)."""
-    img = synthetic_image(load_size, channels, seed)
+def synthetic_body_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor:
+    """[1, C, size, size] in [-1, 1]: a smooth upright silhouette (torso + head + limbs as soft-edged ellipses) on a black
+    background, softly shaded, no pixel noise; channels 3.. of an RGB-D input carry a smooth dome-shaped depth inside the
+    silhouette.  The input of the bench's body-like subject: what a photograph of a person in front of a masked background
+    looks like to the encoders, as opposed to `synthetic_image`'s full-frame texture."""
+    lin = torch.linspace(-1.0, 1.0, size)
+    yy, xx = torch.meshgrid(lin, lin, indexing='ij')
+    parts = [(0.0, 0.05, 0.30, 0.42), (0.0, -0.55, 0.14, 0.16), (-0.16, 0.62, 0.10, 0.30), (0.16, 0.62, 0.10, 0.30),
+             (-0.40, 0.0, 0.09, 0.34), (0.40, 0.0, 0.09, 0.34)]          # (cx, cy, rx, ry)
+    dome = torch.zeros(size, size)
+    for k, (cx, cy, rx, ry) in enumerate(parts):
+        cx = cx + 0.02 * math.sin(1.7 * seed + k)
+        r2 = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2
+        dome = torch.maximum(dome, torch.clamp(1.0 - r2, min=0.0).sqrt())
+    mask = torch.clamp(dome * 6.0, max=1.0)                               # soft edge a few pixels wide
+    img = torch.empty(1, channels, size, size)
+    for c in range(channels):
+        if c < 3:
+            shade = 0.55 + 0.25 * dome + 0.08 * torch.sin(math.pi * (0.8 + 0.3 * c) * xx + 0.5 * c) * torch.cos(math.pi * 0.6 * yy)
+        else:
+            shade = 0.2 + 0.7 * dome                                      # depth-like channels
+        img[0, c] = -1.0 + mask * (shade + 1.0)
+    return img.clamp_(-1.0, 1.0)
+
+
+def synthetic_inputs(load_size: int = 1024, channels: int = 3, seed: int = 0, kind: str = 'texture') -> dict:
+    """Data dict with the keys `gen_mesh` reads (`readData.py:106-116`, `reconstruction.py:29-34`).  kind: 'texture' (the
+    full-frame sinusoid + noise image) or 'body' (`synthetic_body_image`)."""
+    img = synthetic_body_image(load_size, channels, seed) if kind == 'body' else synthetic_image(load_size, channels, seed)
     if load_size == 512:
         img_512 = img.clone()
     else:

@@ -21,16 +21,66 @@ def _data():
             'calib': calib_tensor(), 'b_min': [-1, -1, -1], 'b_max': [1, 1, 1]}
 
 
-def _build():
+def _build(mlp_norm='group'):
     from pifuhd_amd import nets, synth
     from helpers import golden_nets
-    sd, oc, of = golden_nets()
+    sd, oc, of = golden_nets(mlp_norm=mlp_norm)
     of.loadSizeBig = 128
     netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
     data = _data()
     netMR.filter_global(data['img_512']); netMR.filter_local(data['img'][:, None])
     synth.calibrate_occupancy_bias(netMR, data['calib'], sd, 0.3, resolution=32)
     return netMR, data
+
+
+def _pointwise_worker(rank, ws, port, outdir):
+    """The un-normalised MLP of the published pifuhd.pt: the octree levels are dealt out in the library's own groups (16 384
+    rows, no chunk padding) instead of the reference's 5 000-point chunks."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import dist as pdist, reconstruction
+    pdist.SHARDED_MIN_RESOLUTION = 0                   # the 64^3 calls of this test are to exchange, not to fall under the size guard
+    netMR, data = _build('no')
+    assert pdist.effective_chunk(netMR._ctx, 5000, 0) == 16384
+    field = pdist.eval_lattice_sharded(netMR, data['calib'], (48, 64, 64), 5000)
+    sdf, n_eval = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
+    mesh = reconstruction.gen_mesh(64, netMR, 'cuda', data, os.path.join(outdir, f'pw_r{rank}.obj'), sharded=True, result_on='all')
+    np.savez(os.path.join(outdir, f'pw_r{rank}.npz'), field=field.cpu().numpy(), sdf=sdf.cpu().numpy(), n_eval=np.array(n_eval),
+             verts=mesh[0], faces=mesh[1], color=mesh[2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_pointwise_mlp_sharded_matches_single_process(tmp_path):
+    """Two ranks (gloo, one GPU) in the pifuhd.pt configuration (`mlp_norm='no'`): dense lattice in raw Z-slabs, octree levels
+    in 16 384-row groups, gen_mesh end to end - every rank holds the single-process result bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_pointwise_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=800)
+        assert p.exitcode == 0
+    import pifuhd_amd  # noqa: F401
+    from pifuhd_amd import dist as pdist, mesh_util, reconstruction
+    netMR, data = _build('no')
+    field = pdist.eval_lattice_sharded(netMR, data['calib'], (48, 64, 64), 5000).cpu().numpy()
+    sdf, n_eval = mesh_util.eval_grid_device(netMR, data['calib'], 64, 5000, True, init_resolution=16)
+    mesh = reconstruction.gen_mesh(64, netMR, 'cuda', data, str(tmp_path / 'single.obj'))
+    for r in range(2):
+        got = np.load(tmp_path / f'pw_r{r}.npz')
+        assert np.array_equal(got['field'], field)
+        assert np.array_equal(got['sdf'], sdf.cpu().numpy()) and int(got['n_eval']) == n_eval
+        assert all(np.array_equal(got[k], a) for k, a in zip(('verts', 'faces', 'color'), mesh))
+    assert open(tmp_path / 'pw_r0.obj').read() == open(tmp_path / 'single.obj').read()
 
 
 def _worker(rank, ws, port, outdir):
@@ -41,7 +91,8 @@ def _worker(rank, ws, port, outdir):
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=ws)
     import pifuhd_amd  # noqa: F401
-    from pifuhd_amd import reconstruction
+    from pifuhd_amd import dist as pdist0, reconstruction
+    pdist0.SHARDED_MIN_RESOLUTION = 0                  # the 64^3 calls of this test are to exchange, not to fall under the size guard
     netMR, data = _build()
     path = os.path.join(outdir, f'mesh_r{rank}.obj')
     verts, faces, color = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, result_on='all')
@@ -58,6 +109,15 @@ def _worker(rank, ws, port, outdir):
     from pifuhd_amd import dist as pdist
     pdist.SLAB_MC_MIN_RESOLUTION = 64
     verts2, faces2, color2 = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, result_on='all')
+    # the size guard: below dist.SHARDED_MIN_RESOLUTION (128 by default) every rank computes the call alone - no collective,
+    # rank 0 writes and returns, the arrays are the sharded call's
+    pdist0.SHARDED_MIN_RESOLUTION = 128
+    tg = {}
+    guarded = reconstruction.gen_mesh(64, netMR, 'cuda', data, path, sharded=True, timings=tg)
+    assert 'collectives' not in tg and (guarded is None) == (rank != 0)
+    if rank == 0:
+        assert all(np.array_equal(a, b) for a, b in zip(guarded, (verts, faces, color)))
+    pdist0.SHARDED_MIN_RESOLUTION = 0
     # the encoders of the sharded call were dealt out over the two ranks (dist.filter_sharded: netF + fine hourglass on rank 0,
     # netB + coarse hourglass on rank 1, maps broadcast): what every rank holds afterwards
     g = netMR.netG
@@ -115,6 +175,7 @@ def _rccl_worker(port, outdir):
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     import pifuhd_amd  # noqa: F401
     from pifuhd_amd import dist as pdist, reconstruction
+    pdist.SHARDED_MIN_RESOLUTION = 0
     netMR, data = _build()
     want_field = pdist.eval_lattice_sharded(netMR, data['calib'], (40, 32, 48), 5000)
     want_oct, n_want = pdist.eval_grid_octree_sharded(netMR, data['calib'], 64, 5000, init_resolution=16)
@@ -148,9 +209,12 @@ def _rccl_worker(port, outdir):
     finally:
         dist.all_gather_into_tensor = torch_gather
     pdist.release_native_comm()
-    # one all-gather for the dense field; octree levels + colour rounds for the mesh; four more per slab marching cubes
-    native_ran = calls_field == 1 and calls_mesh >= calls_field + 3 and calls_slab >= calls_mesh + (calls_mesh - calls_field) + 4 \
+    # one all-gather for the dense field; per gen_mesh at least one octree level + one colour round; four more for the slab
+    # form of marching cubes (counts, halo planes, vertices, faces)
+    native_ran = calls_field == 1 and calls_mesh >= calls_field + 2 and calls_slab >= calls_mesh + (calls_mesh - calls_field) + 4 \
         and bytes_all > 0
+    print('native communicator calls: field %d, + gen_mesh %d, + slab gen_mesh %d, %d bytes gathered' %
+          (calls_field, calls_mesh, calls_slab, bytes_all), flush=True)
     native_ok = (native_ran and torch.equal(want_field, nat_field) and all(np.array_equal(a, b) for a, b in zip(want, nat))
                  and all(np.array_equal(a, b) for a, b in zip(want, nat_slab))
                  and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'native.obj')).read())
@@ -163,6 +227,8 @@ def _rccl_worker(port, outdir):
           and open(os.path.join(outdir, 'plain.obj')).read() == open(os.path.join(outdir, 'rccl.obj')).read())
     with open(os.path.join(outdir, 'rccl_ok.txt'), 'w') as f:
         f.write('%s %s' % (ok, dist.get_backend()))
+    if not ok:
+        print('rccl worker: native_ran', native_ran, 'native_ok', native_ok, 'calls', calls_field, calls_mesh, calls_slab, flush=True)
     dist.destroy_process_group()
 
 

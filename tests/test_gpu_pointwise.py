@@ -1,0 +1,128 @@
+"""The configuration of the published pifuhd.pt - an MLP without norm layers (`MLP.py:37-41,65-69`) - on the lattice paths:
+the library regroups the work (whole 128-row tiles, whole lattice columns, no statistics passes: `pifu_effective_chunk`)
+instead of cutting it into the reference's 5 000-point query() calls.  Pinned here: (a) the regrouped evaluation is the
+reference's field (CPU oracle in 5 000-point calls, 1e-4); (b) a split of the lattice over ranks at the library's granularity -
+raw Z-slabs of the voxel grid, no chunk padding - reproduces the single-GPU field BIT FOR BIT, for dense ranges and for octree
+index lists; (c) with a norm that couples a chunk nothing is regrouped."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import calib_tensor, golden_nets, seeded_features
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(mlp_norm, mlp_std=None):
+    from pifuhd_amd import nets, synth, config
+    sd, oc, of = golden_nets(mlp_norm=mlp_norm)
+    if mlp_std is not None:      # a field with contrast for the un-normalised MLP (make_golden_r5.py: 0.10)
+        oc = config.coarse_opt(mlp_norm=mlp_norm); of = config.fine_opt(oc)
+        sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=mlp_std, perturb=True)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(7)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    return netG, netMR, sd, oc, of
+
+
+def _eval(netMR, res, first, count, chunk, flags=0, index=None):
+    from pifuhd_amd import _lib, mesh_util
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    calib, calib_inv = mesh_util.calib_pair(calib_tensor())
+    out = torch.empty(count, device='cuda')
+    res_a = (C.c_int32 * 3)(*res)
+    _lib.call('pifu_eval_lattice', netMR._ctx.h, res_a, calib_inv.ctypes.data_as(C.c_void_p), calib.ctypes.data_as(C.c_void_p),
+              _ptr(index) if index is not None else None, first, count, chunk, flags, _ptr(out), _stream_ptr(netMR.device))
+    return out
+
+
+def test_effective_chunk_follows_the_norms():
+    from pifuhd_amd import _lib, dist as pdist
+    _, net_no, *_ = _build('no')
+    _, net_gn, *_ = _build('group')
+    _, net_bn, *_ = _build('batch')          # netG eval (running statistics: pointwise), netMR train (batch statistics: coupled)
+    assert pdist.effective_chunk(net_gn._ctx, 5000, 256) == 5000 and pdist.effective_chunk(net_gn._ctx, 5000, 0) == 5000
+    assert pdist.effective_chunk(net_no._ctx, 5000, 0) == _lib.POINTWISE_CHUNK == 16384
+    assert pdist.effective_chunk(net_no._ctx, 5000, 256) == 16384 and pdist.effective_chunk(net_no._ctx, 100000, 512) == 16384
+    assert pdist.effective_chunk(net_no._ctx, 5000, 48) == 43 * 384          # lcm(128, 48) = 384: whole tiles AND whole columns
+    assert pdist.effective_chunk(net_no._ctx, 5000, 100) == 5 * 3200
+    assert pdist.effective_chunk(net_bn._ctx, 5000, 256) == 5000
+    assert pdist.effective_chunk(net_bn._ctx, 5000, 256, _lib.Q_COARSE_ONLY) == 16384
+
+
+@pytest.mark.parametrize('flags_name', ['default', 'no_depth_walk', 'canonical'])
+def test_pointwise_regrouping_is_the_reference_field(observed, flags_name):
+    """61 440 lattice points in the un-normalised configuration: the library's own grouping against the CPU oracle evaluating
+    the reference's 5 000-point query() calls."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, mesh_util
+    netG, netMR, sd, oc, of = _build('no', mlp_std=0.10)
+    flags = {'default': 0, 'no_depth_walk': _lib.Q_NO_DEPTH_WALK, 'canonical': _lib.Q_NO_COLUMN_SHARING}[flags_name]
+    res = (40, 32, 48)
+    n = res[0] * res[1] * res[2]
+    got = _eval(netMR, res, 0, n, 5000, flags | _lib.Q_FULL_COARSE).cpu().numpy()
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    calib = calib_tensor()
+    _, calib_inv = mesh_util.calib_pair(calib)
+    want = []
+    with torch.no_grad():
+        for s in range(0, n, 5000):
+            flat = np.arange(s, min(s + 5000, n), dtype=np.int64)
+            pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
+            want.append(ref.query(pts, calib)[0, 0].numpy())
+    want = np.concatenate(want)
+    err = float(np.abs(got - want).max())
+    observed(f'pointwise_regrouping[{flags_name}]', gpu_vs_oracle=err, field_std=float(want[want > 0].std()))
+    assert want[want > 0].std() > 0.02          # a field with contrast, not a constant
+    assert np.array_equal(got == 0, want == 0) and err < 1e-4
+
+
+@pytest.mark.parametrize('ws', [2, 3, 8])
+def test_pointwise_slab_split_is_bit_identical(ws):
+    """What `dist.sharded_eval` does with N ranks, rank by rank in one process: every rank's share - whole groups of the
+    library's own granularity, i.e. raw axis-0 slabs of the dense grid - evaluated by its own call, the shares side by side
+    against the single call.  Dense range (columns of 48 nodes: groups of 43 x 384 points) and an octree-style index list."""
+    from pifuhd_amd import dist as pdist
+    netG, netMR, *_ = _build('no', mlp_std=0.10)
+    res = (64, 32, 48)
+    n = res[0] * res[1] * res[2]
+    whole = _eval(netMR, res, 0, n, 5000)
+    eff = pdist.effective_chunk(netMR._ctx, 5000, res[2])
+    parts = []
+    for r in range(ws):
+        first, count, per = pdist.shard_chunks(n, eff, ws, r)
+        assert first % res[2] == 0 and (count % eff == 0 or first + count == n)
+        if count:
+            parts.append(_eval(netMR, res, first, count, 5000))
+    assert torch.equal(torch.cat(parts), whole)
+    # index list: every third lattice node plus a dense stretch (long and short column segments for the depth walk)
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand(n, generator=g) < 0.3)
+    keep[20000:45000] = True
+    index = keep.nonzero()[:, 0].to('cuda', torch.int64).contiguous()
+    m = int(index.numel())
+    whole_l = _eval(netMR, res, 0, m, 5000, index=index)
+    eff_l = pdist.effective_chunk(netMR._ctx, 5000, 0)
+    parts = []
+    for r in range(ws):
+        first, count, per = pdist.shard_chunks(m, eff_l, ws, r)
+        if count:
+            parts.append(_eval(netMR, res, first, count, 5000, index=index))
+    assert torch.equal(torch.cat(parts), whole_l)
+    # and the list evaluation is the dense one at those nodes up to fp32 summation order (segments are cut differently)
+    assert float((whole_l - whole[index]).abs().max()) < 2e-5
+
+
+def test_group_norm_is_never_regrouped():
+    """With GroupNorm the reference's chunk is part of the numbers: a 5 000-point cut and a 4 096-point cut differ, and the
+    library keeps the caller's."""
+    netG, netMR, *_ = _build('group')
+    res = (16, 32, 48)
+    n = res[0] * res[1] * res[2]
+    a = _eval(netMR, res, 0, n, 5000)
+    b = _eval(netMR, res, 0, n, 4096)
+    assert float((a - b).abs().max()) > 1e-6
