@@ -552,7 +552,14 @@ def main():
     _lib.call('pifu_reserve_auto', h, args.batch_rows, 0.5 / (world if one_gpu_test else 1), C.byref(rows_fit))
     batch_rows = int(rows_fit.value)
 
+    def fresh_eval(chunk, fl):
+        _lib.call('pifu_drop_tables', h)      # every measured evaluation rebuilds its column tables, like step()
+        return pdist.eval_lattice_sharded(netMR, calib, res, chunk, fl)
+
     def step():
+        # a step pays for everything a subject's grid evaluation pays for: the per-column tables (sampled features + their
+        # products with the skip weights), which the library would otherwise keep from the previous step, are dropped first
+        _lib.call('pifu_drop_tables', h)
         return pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, flags)
 
     grouped = world > 1 or args.dist_selftest       # a process group exists: barriers / reductions / sharded gen_mesh run
@@ -677,7 +684,7 @@ def main():
     if world == 1 and not args.no_canonical and not args.no_column_sharing:
         try:
             cflags = flags | _lib.Q_NO_COLUMN_SHARING
-            pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, cflags)
+            fresh_eval(args.chunk, cflags)
             fence()
             reset_prof(_lib, h)
             _lib.call('pifu_profile_enable', h, 1)
@@ -685,7 +692,7 @@ def main():
             fence()
             c0 = time.perf_counter()
             for _ in range(args.canonical_steps):
-                field_c = pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, cflags)
+                field_c = fresh_eval(args.chunk, cflags)
             fence()
             c_el = time.perf_counter() - c0
             c_mhz = measured_mhz(ck0, clock_probe())
@@ -779,11 +786,11 @@ def main():
     if world == 1 and not args.lean and not args.no_lean_pass:
         try:
             lean_flags = flags & ~_lib.Q_FULL_COARSE
-            pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, lean_flags)
+            fresh_eval(args.chunk, lean_flags)
             fence()
             l0 = time.perf_counter()
             for _ in range(args.steps):
-                field_lean = pdist.eval_lattice_sharded(netMR, calib, res, args.chunk, lean_flags)
+                field_lean = fresh_eval(args.chunk, lean_flags)
             fence()
             l_el = time.perf_counter() - l0
             out['without_unread_coarse_tail'] = {
@@ -799,13 +806,13 @@ def main():
     # gen_mesh_imgColor / _plus pass num_samples=100000; GroupNorm then spans 100 000 points, so it is a different field)
     if world == 1 and not args.no_chunk100k:
         try:
-            pdist.eval_lattice_sharded(netMR, calib, res, 100000, flags)
+            fresh_eval(100000, flags)
             fence()
             reset_prof(_lib, h)
             _lib.call('pifu_profile_enable', h, 1)
             k0 = time.perf_counter()
             for _ in range(args.steps):
-                pdist.eval_lattice_sharded(netMR, calib, res, 100000, flags)
+                fresh_eval(100000, flags)
             fence()
             k_el = time.perf_counter() - k0
             _lib.call('pifu_profile_enable', h, 0)

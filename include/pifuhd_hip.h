@@ -105,7 +105,8 @@ enum {
  *      a context is still used by ONE call at a time, but consecutive calls may be enqueued on different streams without the
  *      caller synchronising them: every entry point first makes its stream wait for the work of the previous call.
  *   5: round 6 - pifu_enc_set_param_device BORROWS the caller's tensor (no copy, no synchronisation; it must outlive the
- *      registration); pifu_calc_normal_coarse, pifu_reserve_auto, pifu_effective_chunk and PIFU_Q_NO_COARSE_MASK added; calls of more than
+ *      registration); pifu_calc_normal_coarse, pifu_reserve_auto, pifu_effective_chunk, pifu_drop_tables and PIFU_Q_NO_COARSE_MASK added; the
+ *      column tables of a lattice evaluation are kept for later calls on the same inputs; calls of more than
  *      `chunk` points are regrouped when every MLP norm is pointwise (see pifu_effective_chunk); the library exports nothing
  *      but the PIFU_API entry points of this header (-fvisibility=hidden + export map). */
 #define PIFU_ABI_VERSION 5
@@ -167,6 +168,12 @@ PIFU_API int pifu_set_precision(pifu_ctx *ctx, int mode);
  * feature map, the coarse MLP or the precision mode changes. */
 #define PIFU_PIXEL_TABLE_MIN_POINTS 16384
 PIFU_API int pifu_set_pixel_tables(pifu_ctx *ctx, int mode);
+/* Tables derived from the feature maps live in the context until an input changes: the pixel table above and - ABI 5 - the
+ * per-column tables of the lattice evaluations (sampled features of every (i, j) column and their products with the skip
+ * weights), which the levels of one octree evaluation and every later call on the same maps, weights, lattice and calibration
+ * share.  Every setter of an input drops them; pifu_drop_tables does it by hand (a benchmark that must pay for them in every
+ * step, as a new subject would). */
+PIFU_API int pifu_drop_tables(pifu_ctx *ctx);
 /* DepthNormalizer (DepthNormalizer.py:17-24): z_feat = z * z_mul / z_div with z_mul = loadSize // 2,
  * z_div = z_size of the COARSE net's options. */
 PIFU_API int pifu_set_depth_normalizer(pifu_ctx *ctx, float z_mul, float z_div);

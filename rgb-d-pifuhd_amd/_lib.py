@@ -59,6 +59,7 @@ SIGNATURES = {
     'pifu_mlp_set_layer': (_i32, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'pifu_set_precision': (_i32, [_p, _i32]),
     'pifu_set_pixel_tables': (_i32, [_p, _i32]),
+    'pifu_drop_tables': (_i32, [_p]),
     'pifu_set_depth_normalizer': (_i32, [_p, _f, _f]),
     'pifu_set_features': (_i32, [_p, _i32, _p, _i32, _i32, _i32, _p]),
     'pifu_enc_set_param': (_i32, [_p, C.c_char_p, _p, _p, _i32]),

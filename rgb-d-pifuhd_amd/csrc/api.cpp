@@ -277,6 +277,7 @@ extern "C" int pifu_set_precision(pifu_ctx *ctx, int mode)
     }
     ctx->precision = mode;
     ctx->pix.valid = false;            // the pixel table is a product of the GEMM in the current arithmetic
+    ctx->col_cache.valid = false;
     return PIFU_OK;
 }
 
@@ -285,6 +286,16 @@ extern "C" int pifu_set_pixel_tables(pifu_ctx *ctx, int mode)
 {
     PIFU_REQUIRE(ctx && mode >= 0 && mode <= 2, PIFU_ERR_INVALID, "pifu_set_pixel_tables: mode must be 0 (off), 1 (auto) or 2 (always)");
     ctx->pix_mode = mode;
+    return PIFU_OK;
+}
+
+// forget the column tables of the lattice evaluations and the pixel table of the point-list queries: the next call rebuilds
+// them (what a new subject's feature maps do implicitly)
+extern "C" int pifu_drop_tables(pifu_ctx *ctx)
+{
+    PIFU_REQUIRE(ctx, PIFU_ERR_INVALID, "pifu_drop_tables: null context");
+    ctx->col_cache.valid = false;
+    ctx->pix.valid = false;
     return PIFU_OK;
 }
 
@@ -310,6 +321,7 @@ extern "C" int pifu_mlp_define(pifu_ctx *ctx, int level, const int32_t *dims, in
     for (int i = 0; i < PIFU_MAX_LAYERS; ++i) free_layer(m.layer[i]);
     if (m.colW) { (void)hipFree(m.colW); m.colW = nullptr; }
     if (level == 0) ctx->pix.valid = false;
+    ctx->col_cache.valid = false;
     m = Mlp();
     m.ndims = ndims;
     m.nlayers = ndims - 1;
@@ -404,6 +416,7 @@ extern "C" int pifu_mlp_set_layer(pifu_ctx *ctx, int level, int layer, const flo
     for (auto &kv : ctx->bf16_planes) (void)hipFree(kv.second.hi);      // device addresses may be reused by new weights
     ctx->bf16_planes.clear();
     m.col_built = false;
+    ctx->col_cache.valid = false;
     if (level == 0) { ctx->mlp[1].col_built = false; ctx->pix.valid = false; }
     if (l.has_norm) {
         std::vector<float> g(l.cout_pad, 0.f), be(l.cout_pad, 0.f), fs(l.cout_pad, 0.f), fb(l.cout_pad, 0.f);

@@ -453,28 +453,36 @@ __global__ void k_add_stats(const float *A, int lda, const float *B, int ldb, fl
     }
 }
 
-// one wave per group: (sum, sum^2) over blocks and the group's channels -> per-channel scale / shift
-__global__ void k_stats_finalize(const double *partial, int nb, int C, int cpg, int groups, double count_per_channel,
-                                 const float *gamma, const float *beta, float eps, float *scale, float *shift)
+// one BLOCK per group: (sum, sum^2) over the partial rows and the group's channels -> per-channel scale / shift.  (Round 5 ran
+// one wave per group: 2 048 partial rows of a 512^2 map were 32 dependent double loads per lane - 14 - 20 us of pure latency
+// on the critical queue, 55 times per pass.  256 threads take 8 each and meet in a fixed-order tree: ~5 us.)
+__global__ __launch_bounds__(256) void k_stats_finalize(const double *partial, int nb, int C, int cpg, int groups, double count_per_channel,
+                                                        const float *gamma, const float *beta, float eps, float *scale, float *shift)
 {
-    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wid >= groups) return;
+    __shared__ double red[2][256];
+    const int grp = blockIdx.x, tid = threadIdx.x;
     double s = 0, q = 0;
     const int total = nb * cpg;
-    for (int i = lane; i < total; i += 64) {
-        const int b = i / cpg, ch = wid * cpg + i % cpg;
+    for (int i = tid; i < total; i += 256) {
+        const int b = i / cpg, ch = grp * cpg + i % cpg;
         s += partial[((size_t)b * C + ch) * 2];
         q += partial[((size_t)b * C + ch) * 2 + 1];
     }
+    red[0][tid] = s;
+    red[1][tid] = q;
+    __syncthreads();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    for (int o = 128; o > 0; o >>= 1) {      // fixed order: the result does not depend on scheduling
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
     const double cnt = count_per_channel * cpg;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
+    const double mean = red[0][0] / cnt;
+    double var = red[1][0] / cnt - mean * mean;
     var = var > 0 ? var : 0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int i = lane; i < cpg; i += 64) {
-        const int ch = wid * cpg + i;
+    for (int i = tid; i < cpg; i += 256) {
+        const int ch = grp * cpg + i;
         const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
         scale[ch] = (float)(g * rstd);
         shift[ch] = (float)(b - mean * rstd * g);
@@ -580,38 +588,56 @@ __global__ void k_bicubic_up2_add(const float *L, int ldl, int h, int w, const f
     *reinterpret_cast<float4 *>(O + p * ldo + c) = make_float4(u.x + acc.x, u.y + acc.y, u.z + acc.z, u.w + acc.w);
 }
 
-// Build the 32-channel NHWC network input [img (Cimg) | nmlF (3) | nmlB (3) | 0...] at H x W from an NCHW
-// image and NCHW normal maps at (Hn x Wn), bilinear align_corners=True if the sizes differ
-// (PIFuNetwNML.py:84-92, PIFuMRNet.py:99-103).
-__global__ void k_pack_input(const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn,
-                             float *O, int ldo)
+// The network input [img (Cimg) | nmlF (3) | nmlB (3) | 0...] at H x W from an NCHW image and NCHW normal maps at (Hn x Wn)
+// - bilinear align_corners=True if the sizes differ (PIFuNetwNML.py:84-92, PIFuMRNet.py:99-103) - written DIRECTLY in the form
+// the first convolution's LDS-DMA reads: border-padded (zeros, or mirrored pixels for the normal nets' ReflectionPad) NHWC
+// with Cp = roundup(channels, 4) floats per pixel + 64 floats of slack.  (Round 5 wrote a 32-channel NHWC tensor - 134 MB at
+// 1024^2, one thread per pixel storing 128 strided bytes: 203 us - and k_prep_act then copied 12 of the 32 channels into the
+// padded form; this is one pass over 50 MB.)
+__global__ void k_pack_prepared(const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn,
+                                float *P, int Hp, int Wp, int Cp, int pad, int reflect)
 {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (size_t)H * W) return;
-    const int x = (int)(p % W), y = (int)(p / W);
-    float *o = O + p * ldo;
+    const size_t total = (size_t)Hp * Wp;
+    if (p >= total) {
+        if (p < total + 16) *reinterpret_cast<float4 *>(P + total * Cp + (p - total) * 4) = make_float4(0, 0, 0, 0);
+        return;
+    }
+    int y = (int)(p / Wp) - pad, x = (int)(p % Wp) - pad;
+    bool inside = true;
+    if (reflect) {
+        y = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+        x = x < 0 ? -x : (x >= W ? 2 * (W - 1) - x : x);
+        inside = y >= 0 && y < H && x >= 0 && x < W;      // (beyond one mirror length: cannot happen for pad < H)
+    } else {
+        inside = y >= 0 && y < H && x >= 0 && x < W;
+    }
+    float *o = P + p * Cp;
     int c = 0;
-    for (int k = 0; k < Cimg; ++k) o[c++] = img[(size_t)k * H * W + p];
-    const float *srcs[2] = {nF, nB};
-    for (int s = 0; s < 2; ++s) {
-        if (!srcs[s]) continue;
-        if (Hn == H && Wn == W) {
-            for (int k = 0; k < 3; ++k) o[c++] = srcs[s][(size_t)k * H * W + p];
-        } else {
-            const float fy = Hn > 1 ? (float)y * ((float)(Hn - 1) / (float)(H - 1)) : 0.f;
-            const float fx = Wn > 1 ? (float)x * ((float)(Wn - 1) / (float)(W - 1)) : 0.f;
-            const int y0 = min((int)fy, Hn - 1), x0 = min((int)fx, Wn - 1);
-            const int y1 = min(y0 + 1, Hn - 1), x1 = min(x0 + 1, Wn - 1);
-            const float ly = fy - y0, lx = fx - x0;
-            for (int k = 0; k < 3; ++k) {
-                const float *m = srcs[s] + (size_t)k * Hn * Wn;
-                const float v = (1.f - ly) * ((1.f - lx) * m[(size_t)y0 * Wn + x0] + lx * m[(size_t)y0 * Wn + x1]) +
-                                ly * ((1.f - lx) * m[(size_t)y1 * Wn + x0] + lx * m[(size_t)y1 * Wn + x1]);
-                o[c++] = v;
+    if (inside) {
+        const size_t q = (size_t)y * W + x;
+        for (int k = 0; k < Cimg; ++k) o[c++] = img[(size_t)k * H * W + q];
+        const float *srcs[2] = {nF, nB};
+        for (int s = 0; s < 2; ++s) {
+            if (!srcs[s]) continue;
+            if (Hn == H && Wn == W) {
+                for (int k = 0; k < 3; ++k) o[c++] = srcs[s][(size_t)k * H * W + q];
+            } else {
+                const float fy = Hn > 1 ? (float)y * ((float)(Hn - 1) / (float)(H - 1)) : 0.f;
+                const float fx = Wn > 1 ? (float)x * ((float)(Wn - 1) / (float)(W - 1)) : 0.f;
+                const int y0 = min((int)fy, Hn - 1), x0 = min((int)fx, Wn - 1);
+                const int y1 = min(y0 + 1, Hn - 1), x1 = min(x0 + 1, Wn - 1);
+                const float ly = fy - y0, lx = fx - x0;
+                for (int k = 0; k < 3; ++k) {
+                    const float *m = srcs[s] + (size_t)k * Hn * Wn;
+                    const float v = (1.f - ly) * ((1.f - lx) * m[(size_t)y0 * Wn + x0] + lx * m[(size_t)y0 * Wn + x1]) +
+                                    ly * ((1.f - lx) * m[(size_t)y1 * Wn + x0] + lx * m[(size_t)y1 * Wn + x1]);
+                    o[c++] = v;
+                }
             }
         }
     }
-    for (; c < ldo; ++c) o[c] = 0.f;
+    for (; c < Cp; ++c) o[c] = 0.f;
 }
 
 // Last layer of the normal nets: ReflectionPad(3) + Conv7x7 (64 -> 3) + Tanh, NCHW output (networks.py:158-160).
@@ -905,6 +931,12 @@ struct Tensor {
     // left them behind (conv epilogue, k_add_stats) or a norm already reduced them; null: the norm makes its own pass
     double *stat = nullptr;
     int stat_nb = 0;
+    // a tensor that exists ONLY in the prepared form of its (first) consumer (pack_input): border-padded NHWC with pCp floats
+    // per pixel, activation already "applied" (the network input is consumed raw); p is null then
+    const float *prepP = nullptr;
+    int pHp = 0, pWp = 0, pCp = 0, pPad = 0;
+    bool pReflect = false;
+    unsigned pBytes = 0;
     size_t pixels() const { return (size_t)H * W; }
 };
 
@@ -1091,7 +1123,7 @@ Affine norm_affine(EncState &S, const std::string &prefix, Tensor &x, int norm)
         gamma = dev_upload(S, prefix + ".weight", param(S, prefix + ".weight").data);
         beta = dev_upload(S, prefix + ".bias", param(S, prefix + ".bias").data);
     }
-    hipLaunchKernelGGL(k_stats_finalize, dim3(nblk((size_t)groups * 64, 256)), dim3(256), 0, S.cur->st, (const double *)partial, nb, C,
+    hipLaunchKernelGGL(k_stats_finalize, dim3(groups), dim3(256), 0, S.cur->st, (const double *)partial, nb, C,
                        cpg, groups, (double)P, gamma, beta, 1e-5f, sc, sh);
     a.scale = sc;
     a.shift = sh;
@@ -1279,7 +1311,12 @@ void conv2d(EncState &S, const std::string &wname, const std::string &bname, con
         ConvDmaArgs a{};
         a.W = packed_dma_weight(S, wname + "#dma" + std::to_string(Cp) + "_" + std::to_string(tn), wname, wp, false, Cp, co, cout_pad, spans, &a.ldw);
         a.bias = packed_bias(S, bname.empty() ? wname + "#nobias" : bname, cout_pad, !bname.empty());
-        a.P = prepare_input(S, x, act, Cp, g.pad, Hp, Wp, g.reflect, &a.p_bytes);
+        if (x.prepP) {      // the packed network input: already in this convolution's prepared form
+            if (x.pCp != Cp || x.pHp != Hp || x.pWp != Wp || x.pPad != g.pad || x.pReflect != g.reflect || act.slope != 1.f)
+                throw Fail{wname + ": the packed input was prepared for another geometry"};
+            a.P = x.prepP; a.p_bytes = x.pBytes;
+        } else
+            a.P = prepare_input(S, x, act, Cp, g.pad, Hp, Wp, g.reflect, &a.p_bytes);
         a.Wp = Wp; a.C = Cp; a.RW = out.W; a.nrows = nrows; a.is = g.stride;
         a.nspan = g.k;
         for (int ky = 0; ky < g.k; ++ky) {
@@ -1608,11 +1645,20 @@ void global_generator(EncState &S, const std::string &p, const Tensor &in32, flo
     book_conv(S, 2.0 * x.H * x.W * 3.0 * (double)w.shape[1] * 49.0);
 }
 
-Tensor pack_input(EncState &S, const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn)
+// the network input of a 7 x 7 first convolution (pad 3: zeros for the HGFilters, mirrored for the normal nets), in prepared form
+Tensor pack_input(EncState &S, const float *img, int Cimg, int H, int W, const float *nF, const float *nB, int Hn, int Wn, bool reflect)
 {
-    Tensor t = new_tensor(S, H, W, 32);
-    if (Cimg + (nF ? 3 : 0) + (nB ? 3 : 0) > 32) throw Fail{"more than 32 input channels"};
-    hipLaunchKernelGGL(k_pack_input, dim3(nblk(t.pixels(), 256)), dim3(256), 0, S.cur->st, img, Cimg, H, W, nF, nB, Hn, Wn, t.p, t.ld);
+    const int ci = Cimg + (nF ? 3 : 0) + (nB ? 3 : 0), pad = 3;
+    if (ci > 32) throw Fail{"more than 32 input channels"};
+    Tensor t;
+    t.H = H; t.W = W; t.C = 32; t.ld = 32;          // the logical tensor (channels beyond `ci` are zero); it has no unprepared form
+    t.pCp = (int)round_up(ci, 4); t.pHp = H + 2 * pad; t.pWp = W + 2 * pad; t.pPad = pad; t.pReflect = reflect;
+    const size_t floats = (size_t)t.pHp * t.pWp * t.pCp + 64;
+    if (floats * sizeof(float) >= ((size_t)1 << 32)) throw Fail{"prepared network input exceeds 4 GB"};
+    float *P = arena_take(S, floats);
+    t.prepP = P; t.pBytes = (unsigned)(floats * sizeof(float));
+    hipLaunchKernelGGL(k_pack_prepared, dim3(nblk((size_t)t.pHp * t.pWp + 16, 256)), dim3(256), 0, S.cur->st, img, Cimg, H, W, nF, nB, Hn, Wn,
+                       P, t.pHp, t.pWp, t.pCp, pad, reflect ? 1 : 0);
     return t;
 }
 
@@ -1800,7 +1846,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         if ((use_front || use_back) && !normals_given) {
             rc = begin(ctx, S, 0, px * 4 * (size_t)1000 + ((size_t)320 << 20), st);
             if (rc) return rc;
-            Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W);
+            Tensor in = pack_input(S, img_nchw, Cimg, H, W, nullptr, nullptr, H, W, true);
             S.fuse_stats = true;          // every conv of the normal nets is followed by an InstanceNorm
             const bool side = use_front && use_back;
             if (side) {         // lane 1 starts from the packed image, BEFORE anything of netF is in the caller's stream
@@ -1831,7 +1877,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         if (rc) return rc;
         rc = fork_lane(S, 2, st);
         if (rc) return rc;
-        Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W);
+        Tensor in = pack_input(S, img_nchw, Cimg, H, W, use_front ? nmlF : nullptr, use_back ? nmlB : nullptr, H, W, false);
         S.norm = norm;
         S.fuse_stats = norm != 0;         // eval-mode BatchNorm needs no statistics
         std::vector<Tensor> stacks;
@@ -1847,6 +1893,7 @@ extern "C" int pifu_filter_coarse(pifu_ctx *ctx, const float *img_nchw, int Cimg
         }
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
         ctx->pix.valid = false;           // the pixel table of the point-list queries belongs to the previous map
+        ctx->col_cache.valid = false;     // ... and so do the column tables of the lattice evaluations
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
                                   hipMemcpyDeviceToDevice, S.cur->st));
         if (feat_nchw && all_stacks) {      // train mode (PIFuNetwNML.py:94-97 keeps the whole list): [num_stack][C][H/4][W/4]
@@ -1901,7 +1948,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
     S.branch_free = hg_depth >= 2 ? 2 : hg_depth;
     S.branch_next = 3;
     try {
-        Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn);
+        Tensor in = pack_input(S, img_nchw, Cimg, H, W, nmlF, nmlB, Hn, Wn, false);
         S.norm = norm;
         S.fuse_stats = norm != 0;
         Tensor f = hg_filter(S, "fine.image_filter", in, num_stack, hg_depth, hg_dim, false);
@@ -1915,6 +1962,7 @@ extern "C" int pifu_filter_fine(pifu_ctx *ctx, const float *img_nchw, int Cimg, 
             fm.bytes = bytes;
         }
         fm.C = f.C; fm.Cpad = f.C; fm.H = f.H; fm.W = f.W;
+        ctx->col_cache.valid = false;
         PIFU_HIP(hipMemcpy2DAsync(fm.nhwc, f.C * sizeof(float), f.p, f.ld * sizeof(float), f.C * sizeof(float), f.pixels(),
                                   hipMemcpyDeviceToDevice, S.cur->st));
         if (feat_nchw)

@@ -120,6 +120,17 @@ struct pifu_ctx {
     struct SelState { bool valid = false; int R = 0, reso = 0; const uint8_t *notproc = nullptr; int64_t n = 0; } sel;
     // column tables of the lattice evaluation (column sharing)
     DevBuf col_arena;
+    // the tables col_arena holds at the moment (query.hip build_column_tables): the levels of ONE octree evaluation - and every
+    // later call on the same maps, weights, lattice and calibration - share them instead of rebuilding them per call.  Dropped
+    // by every setter of their inputs (feature maps, MLP weights, precision).
+    struct ColCache {
+        bool valid = false;
+        bool fine = false;
+        int res[3] = {0, 0, 0}, ldc = 0, ldf = 0, precision = 0;
+        float calib[12] = {0};
+        double cinv[12] = {0};
+        int64_t col_base = 0, ncols = 0;
+    } col_cache;
     int col_enable = 1;
     int walk_enable = 1;                  // depth walk of coarse layer 1 on lattice sources
     // pixel tables of explicit point lists (query.hip "Pixel tables"): G = W_feat * F over the pixels of the coarse map

@@ -1363,6 +1363,7 @@ int pifu_set_features(pifu_ctx *ctx, int level, const float *feat_nchw, int C, i
     }
     f.C = C; f.Cpad = C; f.H = H; f.W = W;
     if (level == 0) ctx->pix.valid = false;      // the pixel table belongs to the previous map
+    ctx->col_cache.valid = false;
     dim3 grid((H * W + 31) / 32, (C + 31) / 32);
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, feat_nchw, f.nhwc, C, C, H * W);
     PIFU_HIP(hipGetLastError());
@@ -1639,6 +1640,13 @@ static int build_column_tables(pifu_ctx *ctx, bool fine, const SampleArgs &proto
         if (rc) return rc;
     }
     T.col_base = col_base; T.ncols = ncols; T.ncols_pad = round_up(ncols, BM);
+    // the tables of an earlier call on the same inputs (the previous level of the same octree evaluation, typically)
+    pifu_ctx::ColCache &cc = ctx->col_cache;
+    bool hit = cc.valid && cc.fine == fine && cc.ldc == ldc && cc.ldf == ldf && cc.precision == ctx->precision &&
+               cc.col_base == col_base && cc.ncols == ncols && ctx->col_arena.p != nullptr;
+    for (int k = 0; hit && k < 3; ++k) hit = cc.res[k] == proto.src.res[k];
+    for (int k = 0; hit && k < 12; ++k) hit = cc.calib[k] == proto.calib[k] && cc.cinv[k] == proto.src.cinv[k];
+    cc.valid = false;
     Carver c{nullptr};
     for (int pass = 0; pass < 2; ++pass) {
         c = Carver{pass ? (char *)ctx->col_arena.p : nullptr};
@@ -1650,10 +1658,12 @@ static int build_column_tables(pifu_ctx *ctx, bool fine, const SampleArgs &proto
             T.Q[L] = c.take<float>((size_t)T.ncols_pad * T.ldq[L]);
         }
         if (!pass) {
+            if (c.off + 256 > ctx->col_arena.bytes) hit = false;      // (cannot happen for a hit: same sizes as when it was built)
             int rc = pifu_ensure(ctx->col_arena, c.off + 256);
             if (rc) return rc;
         }
     }
+    if (hit) { cc.valid = true; return PIFU_OK; }
     ChunkGeom g;
     g.tpc = (int)(T.ncols_pad / BM); g.chunk = (int)ncols; g.last_len = (int)ncols; g.nchunks = 1;
     SampleArgs sa = proto;
@@ -1677,6 +1687,10 @@ static int build_column_tables(pifu_ctx *ctx, bool fine, const SampleArgs &proto
         if (rc) return rc;
     }
     PIFU_HIP(hipGetLastError());
+    cc.fine = fine; cc.ldc = ldc; cc.ldf = ldf; cc.precision = ctx->precision; cc.col_base = col_base; cc.ncols = ncols;
+    for (int k = 0; k < 3; ++k) cc.res[k] = proto.src.res[k];
+    for (int k = 0; k < 12; ++k) { cc.calib[k] = proto.calib[k]; cc.cinv[k] = proto.src.cinv[k]; }
+    cc.valid = true;
     return PIFU_OK;
 }
 

@@ -224,6 +224,23 @@ def synthetic_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor
     return img.clamp_(-1.0, 1.0)
 
 
+_BODY_PARTS = [(0.0, 0.05, 0.36, 0.48), (0.0, -0.60, 0.17, 0.19), (-0.19, 0.66, 0.13, 0.30), (0.19, 0.66, 0.13, 0.30),
+               (-0.48, 0.0, 0.11, 0.38), (0.48, 0.0, 0.11, 0.38)]          # (cx, cy, rx, ry): torso, head, legs, arms
+
+
+def body_dome(size: int, seed: int = 0) -> torch.Tensor:
+    """[size, size] thickness profile of the synthetic body over [-1, 1]^2 (pixel centres at linspace(-1, 1, size), i.e. the
+    align_corners sampling of `index()`): the union of six ellipsoids' half-heights, 1 on their axes, 0 outside the silhouette."""
+    lin = torch.linspace(-1.0, 1.0, size)
+    yy, xx = torch.meshgrid(lin, lin, indexing='ij')
+    dome = torch.zeros(size, size)
+    for k, (cx, cy, rx, ry) in enumerate(_BODY_PARTS):
+        cx = cx + 0.02 * math.sin(1.7 * seed + k)
+        r2 = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2
+        dome = torch.maximum(dome, torch.clamp(1.0 - r2, min=0.0).sqrt())
+    return dome
+
+
 def synthetic_body_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor:
     """[1, C, size, size] in [-1, 1]: a smooth upright silhouette (torso + head + limbs as soft-edged ellipses) on a black
     background, softly shaded, no pixel noise; channels 3.. of an RGB-D input carry a smooth dome-shaped depth inside the
@@ -231,13 +248,7 @@ def synthetic_body_image(size: int, channels: int = 3, seed: int = 0) -> torch.T
     looks like to the encoders, as opposed to `synthetic_image`'s full-frame texture."""
     lin = torch.linspace(-1.0, 1.0, size)
     yy, xx = torch.meshgrid(lin, lin, indexing='ij')
-    parts = [(0.0, 0.05, 0.30, 0.42), (0.0, -0.55, 0.14, 0.16), (-0.16, 0.62, 0.10, 0.30), (0.16, 0.62, 0.10, 0.30),
-             (-0.40, 0.0, 0.09, 0.34), (0.40, 0.0, 0.09, 0.34)]          # (cx, cy, rx, ry)
-    dome = torch.zeros(size, size)
-    for k, (cx, cy, rx, ry) in enumerate(parts):
-        cx = cx + 0.02 * math.sin(1.7 * seed + k)
-        r2 = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2
-        dome = torch.maximum(dome, torch.clamp(1.0 - r2, min=0.0).sqrt())
+    dome = body_dome(size, seed)
     mask = torch.clamp(dome * 6.0, max=1.0)                               # soft edge a few pixels wide
     img = torch.empty(1, channels, size, size)
     for c in range(channels):
@@ -247,6 +258,90 @@ def synthetic_body_image(size: int, channels: int = 3, seed: int = 0) -> torch.T
             shade = 0.2 + 0.7 * dome                                      # depth-like channels
         img[0, c] = -1.0 + mask * (shade + 1.0)
     return img.clamp_(-1.0, 1.0)
+
+
+def craft_body_mlps(sd, opt_coarse, opt_fine, feat_coarse, seed: int = 0, sharpness: float = 100.0, half_depth: float = 0.3,
+                    ballast: float = 100.0, tail_std: float = 0.01):
+    """Weights of the two SurfaceClassifiers that make the net predict ONE smooth closed body - what a trained PIFuHD does
+    and name-seeded random weights do not (their 0.5 level set is a rough sheet of millions of vertices, or - at small weight
+    scales - a field so flat that the octree never refines).  For synthetic checkpoints only; same architecture, same
+    kernels, same FLOPs: a handful of "wire" channels carry the construction, every other weight stays as drawn.
+
+    The body: |z| < half_depth * H(x, y), H = a linear read-out of the coarse feature map fitted (ridge regression, on the
+    map the given encoders produce for this image) to `1.25 * body_dome - 0.25` - positive inside the silhouette, negative
+    outside, ellipsoidal in profile.  The coarse MLP forms u = H - |z_n| / tau from z and the image features with two
+    LeakyReLU layers (leaky(t) + leaky(-t) = 0.99 |t|), hands it to the fine MLP in phi, and the fine MLP carries it to the
+    logit `sharpness * u`: a sigmoid a voxel or two wide at 512^3, like a trained net's.  Under GroupNorm (MLP.py:37-39)
+    the wires sit in group 0 of every layer beside their own negatives (group mean exactly 0) and a +-`ballast` pair (the
+    group's variance: the statistics of a chunk then scale the wires by 1 + O(1e-4), uniformly, which moves no zero of u).
+    Returns (state dict, fit statistics).  `feat_coarse`: [1, C, H, W] as `netG.im_feat_list[-1]`."""
+    oc, of = opt_coarse, opt_fine
+    mode = oc.mlp_norm if oc.mlp_norm in ('group', 'batch') else 'no'
+    if mode == 'batch' or list(oc.mlp_res_layers) != [2, 3, 4] or list(of.mlp_res_layers) != [1, 2] or int(oc.merge_layer) != 2 \
+            or len(oc.mlp_dim) != 6 or len(of.mlp_dim) != 5:
+        raise NotImplementedError('craft_body_mlps: the reference architecture with mlp_norm group / none')
+    sd = OrderedDict((k, v.clone()) for k, v in sd.items())
+    F = feat_coarse.detach().float().cpu()[0]                              # [C, h, w]
+    C, h, w = F.shape
+    if h != w or C + 1 != oc.mlp_dim[0]:
+        raise ValueError('craft_body_mlps: square coarse map with mlp_dim[0] - 1 channels expected')
+    target = (1.25 * body_dome(h, seed) - 0.25).reshape(-1).double()
+    A = torch.cat([F.reshape(C, -1).T.double(), torch.ones(h * w, 1, dtype=torch.float64)], 1)
+    lam = 1e-3 * float((A * A).mean())
+    sol = torch.linalg.solve(A.T @ A + lam * torch.eye(C + 1, dtype=torch.float64), A.T @ target)
+    fit = A @ sol
+    v, c = sol[:C].float(), float(sol[C])
+    stats = {'fit_rms': float((fit - target).pow(2).mean().sqrt()), 'target_rms': float(target.pow(2).mean().sqrt()),
+             'inside_share_of_map': float((fit > 0).double().mean())}
+    z_scale = float(oc.loadSize // 2) / float(oc.z_size)                   # DepthNormalizer: z_n = z * z_scale
+    tau = half_depth * z_scale
+    gn = mode == 'group'
+    B = float(ballast)
+
+    def layer(prefix, i, wires, n_out):
+        """Rewrite group 0 of layer i: `wires` = [(row, {input column: weight}, bias)] - every wire followed by its negative in
+        the next row -, then the ballast pair, the rest of the group silent; returns the norm's gain for the wires."""
+        W, b = sd[f'{prefix}.filters.{i}.weight'], sd[f'{prefix}.filters.{i}.bias']
+        group = n_out // 32 if gn else 2 * len(wires)
+        W[:group] = 0.0
+        b[:group] = 0.0
+        r = 0
+        for cols, bias in wires:
+            for col, val in cols.items():
+                W[r, col, 0] = val
+                W[r + 1, col, 0] = -val
+            b[r], b[r + 1] = bias, -bias
+            r += 2
+        if gn:
+            if r + 2 > group:
+                raise ValueError('craft_body_mlps: group 0 of %s layer %d is too small' % (prefix, i))
+            b[r], b[r + 1] = B, -B
+            g, be = sd[f'{prefix}.norms.{i}.weight'], sd[f'{prefix}.norms.{i}.bias']
+            g[:group] = 1.0
+            be[:group] = 0.0
+            g[:r] = B * math.sqrt(2.0 / group)                            # = the group's sigma when the wires are small against B
+    nc, nf = 'netG.mlp', 'mlp'
+    d = oc.mlp_dim
+    # coarse layer 0: +-z_n, +-H
+    layer(nc, 0, [({C: 1.0}, 0.0), ({k: float(v[k]) for k in range(C)}, c)], d[1])
+    # coarse layer 1: 0.99 |z_n| = leaky(z_n) + leaky(-z_n); 1.01 H = leaky(H) - leaky(-H)
+    layer(nc, 1, [({0: 1.0, 1: 1.0}, 0.0), ({2: 1.0, 3: -1.0}, 0.0)], d[2])
+    # coarse layer 2 (skip layer: inputs [previous | features]): u = H - |z_n| / tau  -> phi
+    layer(nc, 2, [({2: 1.0 / 1.01 ** 2, 3: -1.0 / 1.01 ** 2, 0: -1.0 / (0.99 * tau)}, 0.0)], d[3])
+    # fine MLP: inputs [fine features (16) | phi]; the wire pair leaky(u), leaky(-u) -> 1.01 u per layer
+    cf = of.mlp_dim[0] - d[3]
+    layer(nf, 0, [({cf + 0: 1.0, cf + 1: -1.0}, 0.0)], of.mlp_dim[1])
+    layer(nf, 1, [({0: 1.0, 1: -1.0}, 0.0)], of.mlp_dim[2])
+    layer(nf, 2, [({0: 1.0, 1: -1.0}, 0.0)], of.mlp_dim[3])
+    last = len(of.mlp_dim) - 2
+    gen = torch.Generator().manual_seed((fnv1a64('craft_body_tail') ^ seed) & 0x7FFFFFFFFFFFFFFF)
+    Wl = sd[f'{nf}.filters.{last}.weight']
+    Wl.copy_(torch.randn(Wl.shape, generator=gen) * tail_std)             # what the other channels add: a sub-voxel ripple
+    if gn:
+        Wl[0, :of.mlp_dim[3] // 32, 0] = 0.0                              # (the ballast pair of the last hidden layer)
+    Wl[0, 0, 0], Wl[0, 1, 0] = sharpness / 1.01 ** 3, -sharpness / 1.01 ** 3
+    sd[f'{nf}.filters.{last}.bias'].zero_()
+    return sd, stats
 
 
 def synthetic_inputs(load_size: int = 1024, channels: int = 3, seed: int = 0, kind: str = 'texture') -> dict:

@@ -58,17 +58,24 @@ def main():
             for k in list(sd):
                 if ('image_filter.l' in k) and (k.endswith('.weight') or k.endswith('.bias')) and k.split('.')[-2].startswith('l'):
                     sd[k] = sd[k] * fscale
-        if sharp != 1.0:          # the last layer of the fine MLP feeds the sigmoid alone: a steeper occupancy, the same level set
+        if sharp != 1.0 and kind != 'crafted':          # the last layer of the fine MLP feeds the sigmoid alone: a steeper occupancy, the same level set
             last = 'mlp.filters.%d.weight' % (len(of.mlp_dim) - 2)
             sd[last] = sd[last] * sharp
         netG, netMR = nets.build_nets(oc, of, sd, dev)
-        data = synth.synthetic_inputs(1024, args.channels, seed=0, kind=kind)
+        crafted = kind == 'crafted'
+        data = synth.synthetic_inputs(1024, args.channels, seed=0, kind='body' if crafted else kind)
         if zoom != 1.0:
             data['calib'] = data['calib'].clone()
             data['calib'][0, :3, :3] *= zoom
         netMR.filter_global(data['img_512'].to(dev))
         netMR.filter_local(data['img'].to(dev)[:, None])
-        shift = synth.calibrate_occupancy_bias(netMR, data['calib'], sd, frac)
+        if crafted:      # the MLPs rewritten so that the net predicts one smooth closed body (synth.craft_body_mlps); no bias calibration
+            sd, st = synth.craft_body_mlps(sd, oc, of, netG.im_feat_list[-1], sharpness=100.0 * sharp)
+            print('crafted:', st, flush=True)
+            netMR.load_state_dict(sd)
+            shift = 0.0
+        else:
+            shift = synth.calibrate_occupancy_bias(netMR, data['calib'], sd, frac)
         with tempfile.TemporaryDirectory() as td:
             try:
                 recon.gen_mesh(args.res, netMR, dev, data, os.path.join(td, 'w.obj'))
