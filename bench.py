@@ -117,6 +117,60 @@ def smoother_subject(args, dev, data):
     return netMR2
 
 
+def reserve_share(_lib, net, max_rows, share):
+    """Batch workspace of a context sized from the device's free memory (pifu_reserve_auto): `share` of it at most."""
+    rows = C.c_int64(0)
+    _lib.call('pifu_reserve_auto', net._ctx.h, int(max_rows), float(share), C.byref(rows))
+    return int(rows.value)
+
+
+def body_subject(args, dev, mlp_norm, norm, mlp_std, share=0.25, net=None, sd=None):
+    """The body-like subject: the silhouette image (synth.synthetic_body_image) through the real encoders, and the two MLPs
+    rewritten so that the net predicts ONE smooth closed body (synth.craft_body_mlps: a handful of wire channels in an
+    otherwise name-seeded network; same architecture, kernels and FLOPs).  What a trained PIFuHD produces - a few hundred
+    thousand vertices, an octree that refines a thin shell (2 - 4 % of the grid) - and name-seeded random weights do not.
+    Returns (netG, netMR, data, fit statistics); `net` / `sd`: reuse an existing net of the same configuration."""
+    from pifuhd_amd import config, nets, synth
+    data_b = synth.synthetic_inputs(1024, args.image_channels, seed=0, kind='body')
+    if net is None:
+        oc = config.coarse_opt(in_image_channels=args.image_channels, mlp_norm=mlp_norm, norm=norm)
+        of = config.fine_opt(oc)
+        sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=mlp_std)
+        netG_b, net = nets.build_nets(oc, of, sd, dev)
+        reserve_share(_lib_mod(), net, 1048576, share)
+    else:
+        netG_b = net.netG
+    net.filter_global(data_b['img_512'].to(dev))
+    net.filter_local(data_b['img'].to(dev)[:, None])
+    sd_b, stats = synth.craft_body_mlps(sd, netG_b.opt, net.opt, netG_b.im_feat_list[-1])
+    net.load_state_dict(sd_b)
+    return netG_b, net, data_b, stats
+
+
+def _lib_mod():
+    from pifuhd_amd import _lib
+    return _lib
+
+
+def mesh_components(net, faces):
+    """(connected components, watertight ones, faces of the largest) of a triangle list (pifu_face_components)."""
+    import numpy as np
+    import torch
+    from pifuhd_amd import _lib
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    ctx = net._ctx
+    f = torch.from_numpy(np.ascontiguousarray(faces, dtype=np.int32)).to(ctx.device)
+    label = torch.empty(len(f), device=ctx.device, dtype=torch.int32)
+    flag = torch.empty(len(f), device=ctx.device, dtype=torch.uint8)
+    _lib.call('pifu_face_components', ctx.h, _ptr(f), len(f), _ptr(label), _ptr(flag), _stream_ptr(ctx.device))
+    lab, fl = label.cpu().numpy(), flag.cpu().numpy()
+    roots, inv, cnt = np.unique(lab, return_inverse=True, return_counts=True)
+    leaky = np.zeros(len(roots), bool)
+    np.logical_or.at(leaky, inv, (fl & 1) != 0)
+    return {'components': int(len(roots)), 'watertight_components': int((~leaky).sum()), 'faces_of_largest': int(cnt.max()),
+            'largest_is_watertight': bool(~leaky[int(cnt.argmax())])}
+
+
 def gen_mesh_on_roofline(recon, _lib, netMR, dev, data, res, runs, td, tag, log, cold=None):
     """`runs` timed gen_mesh calls of one subject at `res`^3 after a warm-up call at that size (arenas, pinned result slabs,
     pixel table), the median run's phases, and the call on the roofline: ALGORITHMIC FLOPs executed by one call (MLP GEMM
@@ -448,6 +502,8 @@ def main():
     ap.add_argument('--config5-res', type=int, default=1024,
                     help='resolution of the BASELINE configs[4] leg (one subject, sharded over all ranks at N > 1; 0 = skip)')
     ap.add_argument('--no-smooth-genmesh', action='store_true', help='skip the second gen_mesh subject (stock-scale MLP weights)')
+    ap.add_argument('--no-body-subject', action='store_true', help='skip the body-like gen_mesh subject (crafted smooth closed body)')
+    ap.add_argument('--no-pifuhd-pt', action='store_true', help="skip the pifuhd.pt configuration (GroupNorm filters, MLP without norm layers)")
     ap.add_argument('--image-channels', type=int, default=6, choices=[3, 6],
                     help='6 = RGB-D input (RGB || depth, BASELINE config 2; SURVEY C-7), 3 = RGB as the reference is committed')
     ap.add_argument('--features', choices=['filter', 'synthetic'], default='filter',
@@ -1077,6 +1133,113 @@ def main():
                 except Exception as e:
                     out['gen_mesh']['smoother_subject'] = {'error': repr(e)}
 
+            # ---- the BODY-LIKE subject (what a trained net produces): one smooth closed body, a few hundred thousand vertices, an
+            # octree that refines a thin shell of the grid.  Encoders, per-level synchronisations and small launches weigh here
+            # what the GEMMs weigh on the rough headline subject; the same roofline block prices them.
+            if not args.no_body_subject and 'error' not in out['gen_mesh']:
+                try:
+                    _, net_b, data_b, fit_b = body_subject(args, dev, 'group', 'batch', 0.16)
+                    gb, tb, _, _ = gen_mesh_on_roofline(recon, _lib, net_b, dev, data_b, args.genmesh_res, args.genmesh_runs, td, 'body', log)
+                    gb.update(octree_share(mesh_util, net_b, data_b['calib'], args.genmesh_res))
+                    mb = recon.gen_mesh(args.genmesh_res, net_b, dev, data_b, os.path.join(td, 'body_check.obj'))
+                    drop('body_check.obj')
+                    gb['mesh'] = mesh_components(net_b, mb[1])
+                    gb['subject'] = ('synthetic body image through the encoders; MLPs = name-seeded weights (std 0.16, GroupNorm) with '
+                                     'the wire channels of synth.craft_body_mlps: |z| < 0.3 * H(x, y), H a ridge read-out of the coarse '
+                                     'feature map fitted to the silhouette\'s ellipsoidal profile')
+                    gb['fit'] = {k: round(v, 4) for k, v in fit_b.items()}
+                    out['gen_mesh']['body_subject'] = gb
+                    del net_b, mb
+                except Exception as e:
+                    out['gen_mesh']['body_subject'] = {'error': repr(e)}
+            # ---- the configuration of the published pifuhd.pt (what `recon()` loads, reconstruction.py:233-292):
+            # GroupNorm HGFilters and an MLP WITHOUT norm layers (MLP.py:37-41,65-69).  A point's occupancy then does not depend
+            # on the query() call it is evaluated in: no statistics passes, the lattice cut into whole tiles / whole columns
+            # instead of 5 000-point chunks (pifu_effective_chunk), raw Z-slabs across ranks.  Both halves of the metric: M1 on
+            # the 256^3 lattice (name-seeded weights, std 0.10: the parity fixture e2e_full_pifuhd's), M2 at 512^3 on the
+            # body-like subject, the same roofline blocks.
+            if not args.no_pifuhd_pt:
+                try:
+                    ocp = config.coarse_opt(in_image_channels=args.image_channels, mlp_norm='no', norm='group')
+                    ofp = config.fine_opt(ocp)
+                    sdp = synth.name_seeded_state_dict(synth.state_dict_spec(ocp, ofp), seed=0, mlp_std=0.10)
+                    netGp, netp = nets.build_nets(ocp, ofp, sdp, dev)
+                    hp = netp._ctx.h
+                    rows_p = reserve_share(_lib, netp, args.batch_rows, 0.25)
+                    netp.filter_global(data['img_512'].to(dev))
+                    netp.filter_local(data['img'].to(dev)[:, None])
+                    synth.calibrate_occupancy_bias(netp, calib, sdp, 0.3)
+
+                    def step_p():
+                        _lib.call('pifu_drop_tables', hp)
+                        return pdist.eval_lattice_sharded(netp, calib, res, args.chunk, flags)
+                    step_p()
+                    fence()
+                    reset_prof(_lib, hp)
+                    _lib.call('pifu_profile_enable', hp, 1)
+                    p0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        field_p = step_p()
+                    fence()
+                    p_el = time.perf_counter() - p0
+                    _lib.call('pifu_profile_enable', hp, 0)
+                    pg_ms, pg_n, pg_fl = read_prof(_lib, hp, _lib.PROF_GEMM)
+                    pw_ms, pw_n, pw_by = read_prof(_lib, hp, _lib.PROF_WALK)
+                    p_ach = pg_fl / (pg_ms * 1e-3) / 1e12 if pg_ms > 0 else 0.0
+                    occ = {'value': round(total * args.steps / p_el / 1e6, 3), 'unit': 'Mqueries/s', 'steps': args.steps,
+                           'ms_per_step': round(p_el / max(args.steps, 1) * 1e3, 3),
+                           'workload': f'dense {res[0]}x{res[1]}x{res[2]} lattice, reference chunk {args.chunk} regrouped by the library',
+                           'library_group_rows': pdist.effective_chunk(netp._ctx, args.chunk, res[2], flags), 'batch_rows': rows_p,
+                           'gemm_flop_per_query_executed': round(pg_fl / max(total * args.steps, 1)),
+                           'roofline': {'kernel': 'k_mlp_gemm_tri', 'bound': 'mfma', 'achieved': round(p_ach, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
+                                        'unit': 'TFLOP/s', 'frac': round(p_ach / PEAK_FP32_MATRIX_TFLOPS, 4), 'launches': pg_n,
+                                        'avg_launch_ms': round(pg_ms / max(pg_n, 1), 4),
+                                        'gemm_time_share_of_step': round(pg_ms * 1e-3 / p_el, 4)},
+                           'k_walk_ms_per_step': round(pw_ms / max(args.steps, 1), 3), 'k_walk_launches': pw_n}
+                    if not args.no_cpu_baseline:      # parity of this configuration's field against the CPU oracle (ten chunks)
+                        from oracle import pifu_oracle as O
+                        refp = O.OracleNets(sdp, ocp, ofp, fine_training=True)
+                        refp.feat_coarse, refp.feat_fine = netGp.im_feat_list[-1].cpu(), netp.im_feat_list[-1].cpu()
+                        cinv_p = np.linalg.inv(calib[0].numpy().astype(np.float64))
+                        first_p = (total // 2 // args.chunk) * args.chunk
+                        wants = []
+                        with torch.no_grad():
+                            for c in range(10):
+                                flat = np.arange(first_p + c * args.chunk, first_p + (c + 1) * args.chunk, dtype=np.int64)
+                                pts = torch.from_numpy(O.grid_points_rect(res, cinv_p, flat).astype(np.float32))[None]
+                                wants.append(refp.query(pts, calib)[0, 0])
+                        wantp = torch.cat(wants).numpy()
+                        occ['parity_check_max_abs_diff'] = float(np.abs(field_p[first_p:first_p + len(wantp)].cpu().numpy() - wantp).max())
+                        occ['parity_sample'] = f'{len(wantp)} queries from the middle of the lattice against oracle/pifu_oracle.py in {args.chunk}-point calls'
+                    log(f"pifuhd.pt configuration: {occ['value']} Mq/s, GEMM {p_ach:.1f} TFLOP/s")
+                    pt = {'configuration': "norm='group' (GroupNorm HGFilters), mlp_norm='no' (MLP.py:37-41: no norm layers), name-seeded "
+                                           "weights with MLP std 0.10 (tests/golden/e2e_full_pifuhd.npz pins this configuration end to end)",
+                          'occupancy': occ}
+                    # M2 on the name-seeded weights themselves: a rough sheet through most of the volume - the GEMM-bound end
+                    tr = {}
+                    recon.gen_mesh(args.genmesh_res, netp, dev, data, os.path.join(td, 'pt_rough_warm.obj'))
+                    drop('pt_rough_warm.obj')
+                    recon.gen_mesh(args.genmesh_res, netp, dev, data, os.path.join(td, 'pt_rough.obj'), timings=tr)
+                    drop('pt_rough.obj')
+                    pt['gen_mesh_name_seeded_weights'] = {'resolution': args.genmesh_res,
+                                                          **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in tr.items()},
+                                                          **octree_share(mesh_util, netp, calib, args.genmesh_res)}
+                    # M2 on the body-like subject (the same net object: body image through its encoders, MLPs crafted)
+                    _, _, data_pb, fit_pb = body_subject(args, dev, 'no', 'group', 0.10, net=netp, sd=sdp)
+                    gp, _, _, _ = gen_mesh_on_roofline(recon, _lib, netp, dev, data_pb, args.genmesh_res, args.genmesh_runs, td, 'pt_body', log)
+                    gp.update(octree_share(mesh_util, netp, data_pb['calib'], args.genmesh_res))
+                    mp_ = recon.gen_mesh(args.genmesh_res, netp, dev, data_pb, os.path.join(td, 'pt_body_check.obj'))
+                    drop('pt_body_check.obj')
+                    gp['mesh'] = mesh_components(netp, mp_[1])
+                    gp['fit'] = {k: round(v, 4) for k, v in fit_pb.items()}
+                    pt['gen_mesh'] = gp
+                    out['pifuhd_pt_config'] = pt
+                    del netp, netGp, mp_
+                except Exception as e:
+                    out['pifuhd_pt_config'] = {'error': repr(e)}
+                    log(f'pifuhd.pt configuration failed: {e!r}')
+                finally:
+                    _lib.call('pifu_profile_enable', h, 0)
             # ---- CPU baseline for the second half of the metric: the oracle's gen_mesh phases (octree grid evaluation,
             # serial Lewiner marching cubes, the calc_normal colour loop) at a resolution the host finishes in seconds,
             # with the GPU run at the SAME resolution beside it.  The encoders are left out on the CPU side (minutes there):

@@ -224,8 +224,8 @@ def synthetic_image(size: int, channels: int = 3, seed: int = 0) -> torch.Tensor
     return img.clamp_(-1.0, 1.0)
 
 
-_BODY_PARTS = [(0.0, 0.05, 0.36, 0.48), (0.0, -0.60, 0.17, 0.19), (-0.19, 0.66, 0.13, 0.30), (0.19, 0.66, 0.13, 0.30),
-               (-0.48, 0.0, 0.11, 0.38), (0.48, 0.0, 0.11, 0.38)]          # (cx, cy, rx, ry): torso, head, legs, arms
+_BODY_PARTS = [(0.0, 0.05, 0.36, 0.48), (0.0, -0.54, 0.17, 0.20), (-0.19, 0.64, 0.13, 0.30), (0.19, 0.64, 0.13, 0.30),
+               (-0.42, -0.02, 0.12, 0.38), (0.42, -0.02, 0.12, 0.38)]        # (cx, cy, rx, ry): torso, head, legs, arms - overlapping
 
 
 def body_dome(size: int, seed: int = 0) -> torch.Tensor:
