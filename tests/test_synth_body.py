@@ -43,6 +43,6 @@ def test_crafted_mlps_predict_the_analytic_body(mlp_norm, mlp_std):
     wrong = (p > 0.5) != (u > 0)
     assert int((wrong & (u.abs() > 0.05)).sum()) == 0 and float(wrong.float().mean()) < 0.005
     assert 0.03 < float((u > 0).float().mean()) < 0.10
-    # a sharp sigmoid: away from a thin shell the occupancy is saturated, like a trained net's
-    far = u.abs() > 0.1
+    # away from a shell around the surface the occupancy is saturated, like a trained net's
+    far = u.abs() > 0.35
     assert float(torch.minimum(p[far], 1 - p[far]).max()) < 1e-3
