@@ -101,7 +101,7 @@ def rccl_choices(path):
             'transports': sorted(set(re.findall(r'via ([A-Za-z0-9/_]+)', text)))}
 
 
-def smoother_subject(args, dev, data):
+def smoother_subject(args, dev, data, share=None):
     """The second bench subject: the same image and architecture with the MLP weights drawn at torch's stock scale (std
     0.02 instead of the 0.16 that gives the headline subject its rough, multi-million-vertex surface).  Fewer points survive
     the octree and fewer vertices need normals - the other end of what a reconstruction can look like.  Returns netMR with
@@ -111,6 +111,8 @@ def smoother_subject(args, dev, data):
     of = config.fine_opt(oc)
     sd2 = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=0, mlp_std=0.02)
     _, netMR2 = nets.build_nets(oc, of, sd2, dev)
+    if share is not None:      # several ranks on one card (PIFU_BENCH_ONE_GPU): this context's batch workspace takes its share only
+        reserve_share(_lib_mod(), netMR2, 1048576, share)
     netMR2.filter_global(data['img_512'].to(dev))
     netMR2.filter_local(data['img'].to(dev)[:, None])
     synth.calibrate_occupancy_bias(netMR2, data['calib'], sd2, 0.3)
@@ -421,7 +423,17 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
         # net's looks like, and its mesh stays in the millions of vertices at this resolution.
         if args.config5_res > 0:
             timings = {}
-            net5, err = guarded('config 5 (building the smoother subject)', lambda: smoother_subject(args, dev, data))
+            # the legs above are done with the headline net: its batch workspace goes back to the device first (set and lift a
+            # bound: pifu_set_workspace_limit releases an arena above it) - ranks that SHARE a card need the room for the
+            # 1024^3 state (9.6 GB of SDF + mask, 11.5 GB of column tables, the slab's marching-cubes volumes, per rank)
+            one_gpu = os.environ.get('PIFU_BENCH_ONE_GPU') == '1'
+            if one_gpu:
+                _lm = _lib_mod()
+                _lm.call('pifu_set_workspace_limit', netMR._ctx.h, 1)
+                _lm.call('pifu_set_workspace_limit', netMR._ctx.h, 0)
+                torch.cuda.empty_cache()
+            net5, err = guarded('config 5 (building the smoother subject)',
+                                lambda: smoother_subject(args, dev, data, share=(0.25 / world) if one_gpu else None))
             fence()
 
             def leg_c():
@@ -1003,7 +1015,7 @@ def main():
             _, npts_alt, cpu_s_alt = time_oracle(all_cores, npts // args.chunk, args.cpu_seconds)
             torch.set_num_threads(ncores)
             out['cpu_baseline'].update({
-                'cores_alt': all_cores, 'value_alt': round(npts_alt / cpu_s_alt / 1e6, 4),
+                'cores_alt': all_cores, 'value_alt': round(npts_alt / cpu_s_alt / 1e6, 6),
                 'sample_alt': f'{npts_alt} queries of the same sample in {cpu_s_alt:.1f} s on all {all_cores} host threads',
                 'faster_choice': 'cores' if npts / cpu_s >= npts_alt / cpu_s_alt else 'cores_alt'})
             log(f'cpu baseline on all {all_cores} threads: {npts_alt} queries in {cpu_s_alt:.1f} s')

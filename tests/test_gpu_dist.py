@@ -370,6 +370,12 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert oss['world'] == 2 and oss['result_on'] == 'rank0' and oss['collectives'] >= 2 and oss['collective_bytes'] > 0
     assert oss['collective_s'] >= 0 and oss['collective_s_max_over_ranks'] >= 0 and oss['colour_rounds'] >= 1
     assert gm['independent_subjects']['warmed'] is True and gm['host_threads_per_rank_independent_subjects'] >= 2
+    # round 6: what of the sharded call does not shrink with N, from the call's own measurements (a bad curve explains itself)
+    parts = oss['predicted_fixed_parts']
+    assert set(parts) == {'encoder_chain_s', 'replicated_s', 'collective_s', 'png_s', 'obj_tail_s'} and oss['replicated_s'] > 0
+    assert abs(oss['predicted_fixed_s'] - sum(parts.values())) < 1e-3 and 0 < oss['predicted_fixed_s'] <= oss['total_s'] * 1.001
+    assert abs(oss['predicted_fixed_s'] + oss['shrinking_s'] - oss['total_s']) < 2e-3 and oss['speedup_ceiling_vs_this_run'] >= 1.0
+    assert line['config']['batch_rows'] <= line['config']['batch_rows_requested']       # sized from the card's free memory
     assert 'error' not in gm['config5_1024'], gm['config5_1024']
     assert gm['config5_1024']['mesh_identical_on_all_ranks'] and gm['config5_1024']['n_verts'] > 0
 
@@ -552,3 +558,15 @@ def test_bench_single_gpu_line_carries_every_contract_field():
     assert cg['resolution'] == 64 and cg['value'] > 0
     assert cg['gpu_same_resolution']['max_abs_diff_sdf'] < 1e-4 and cg['gpu_same_resolution']['same_points_evaluated']
     assert {x['bound'] for x in d['roofline_secondary']} >= {'hbm'}
+    # round 6: the body-like subject and the pifuhd.pt configuration (GroupNorm filters, MLP without norm layers), each with the
+    # same roofline block as the headline subject; the CPU baseline at both thread counts
+    for blk in (g['body_subject'], d['pifuhd_pt_config']['gen_mesh']):
+        assert 'error' not in blk and blk['n_verts'] > 0 and blk['mesh']['components'] >= 1 and blk['points_evaluated'] > 0
+        ro2 = blk['roofline']
+        assert ro2['bound'] == 'mfma' and abs(ro2['frac'] - ro2['executed_tflop_per_call'] / blk['total_s'] / 157.3) < 2e-3
+        assert {'reconstruction', 'normals', 'encoders'} <= set(ro2)
+    po = d['pifuhd_pt_config']['occupancy']
+    assert po['value'] > 0 and po['library_group_rows'] % 128 == 0 and po['library_group_rows'] % 64 == 0 and po['parity_check_max_abs_diff'] < 1e-4
+    assert abs(po['roofline']['frac'] - po['roofline']['achieved'] / 157.3) < 1e-3
+    if cb['cores'] != (os.cpu_count() or 1):
+        assert cb['cores_alt'] == os.cpu_count() and cb['value_alt'] > 0 and cb['faster_choice'] in ('cores', 'cores_alt')
