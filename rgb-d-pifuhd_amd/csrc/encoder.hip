@@ -588,6 +588,102 @@ __global__ void k_bicubic_up2_add(const float *L, int ldl, int h, int w, const f
     *reinterpret_cast<float4 *>(O + p * ldo + c) = make_float4(u.x + acc.x, u.y + acc.y, u.z + acc.z, u.w + acc.w);
 }
 
+// The same two element-wise producers with the statistics of what they write in the same pass (block geometry and partial
+// layout of k_channel_stats / k_add_stats: a block owns `rows_per_block` consecutive output pixels, thread (c4, tr) walks its
+// rows in a fixed order).  Their outputs are the inputs of ConvBlocks whose first norm works on batch / group statistics
+// (train-mode BatchNorm of the fine level, GroupNorm): k_channel_stats used to re-read the whole tensor for them
+// (14 launches, 0.5 ms of a pass).
+__global__ void k_avgpool2_stats(const float *X, int ldx, int Win, float *O, int ldo, int C, int Ho, int Wo, int rows_per_block,
+                                 double *partial /* [nb][C][2] */)
+{
+    __shared__ double sh[256 * 2];
+    const int cg = C / 4, P = Ho * Wo;
+    const int tpr = blockDim.x / cg > 0 ? blockDim.x / cg : 1;
+    const int c4 = threadIdx.x % cg, tr = threadIdx.x / cg;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < tpr && c4 < cg) {
+        for (int r = r0 + tr; r < r1; r += tpr) {
+            const int ox = r % Wo, oy = r / Wo;
+            const float *src = X + ((size_t)(2 * oy) * Win + 2 * ox) * ldx + c4 * 4;
+            const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + ldx);
+            const float4 d = *reinterpret_cast<const float4 *>(src + (size_t)Win * ldx), e = *reinterpret_cast<const float4 *>(src + (size_t)Win * ldx + ldx);
+            const float4 v = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
+                                         (a.w + b.w + d.w + e.w) * 0.25f);
+            *reinterpret_cast<float4 *>(O + (size_t)r * ldo + c4 * 4) = v;
+            s[0] += v.x; q[0] = fmaf(v.x, v.x, q[0]); s[1] += v.y; q[1] = fmaf(v.y, v.y, q[1]);
+            s[2] += v.z; q[2] = fmaf(v.z, v.z, q[2]); s[3] += v.w; q[3] = fmaf(v.w, v.w, q[3]);
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        __syncthreads();
+        sh[threadIdx.x * 2] = s[k];
+        sh[threadIdx.x * 2 + 1] = q[k];
+        __syncthreads();
+        if (tr == 0 && c4 < cg) {
+            double ds = 0, dq = 0;
+            for (int t = 0; t < tpr; ++t) { ds += sh[(t * cg + c4) * 2]; dq += sh[(t * cg + c4) * 2 + 1]; }
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2] = ds;
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2 + 1] = dq;
+        }
+    }
+}
+
+__global__ void k_bicubic_up2_add_stats(const float *L, int ldl, int h, int w, const float *U, int ldu, float *O, int ldo, int C,
+                                        int rows_per_block, double *partial /* [nb][C][2] */)
+{
+    __shared__ double sh[256 * 2];
+    const int cg = C / 4, H = 2 * h, Wd = 2 * w, P = H * Wd;
+    const int tpr = blockDim.x / cg > 0 ? blockDim.x / cg : 1;
+    const int c4 = threadIdx.x % cg, tr = threadIdx.x / cg;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+    const float sy = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = w > 1 ? (float)(w - 1) / (float)(Wd - 1) : 0.f;
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < tpr && c4 < cg) {
+        const int c = c4 * 4;
+        for (int r = r0 + tr; r < r1; r += tpr) {
+            const int ox = r % Wd, oy = r / Wd;
+            const float fy = sy * oy, fx = sx * ox;
+            const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+            float wy[4], wx[4];
+            cubic_coeffs(fy - iy, wy);
+            cubic_coeffs(fx - ix, wx);
+            float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), h - 1);
+                float4 row = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = min(max(ix - 1 + b, 0), w - 1);
+                    const float4 v = *reinterpret_cast<const float4 *>(L + ((size_t)yy * w + xx) * ldl + c);
+                    row.x = fmaf(v.x, wx[b], row.x); row.y = fmaf(v.y, wx[b], row.y);
+                    row.z = fmaf(v.z, wx[b], row.z); row.w = fmaf(v.w, wx[b], row.w);
+                }
+                acc.x = fmaf(row.x, wy[a], acc.x); acc.y = fmaf(row.y, wy[a], acc.y);
+                acc.z = fmaf(row.z, wy[a], acc.z); acc.w = fmaf(row.w, wy[a], acc.w);
+            }
+            const float4 u = *reinterpret_cast<const float4 *>(U + (size_t)r * ldu + c);
+            const float4 v = make_float4(u.x + acc.x, u.y + acc.y, u.z + acc.z, u.w + acc.w);
+            *reinterpret_cast<float4 *>(O + (size_t)r * ldo + c) = v;
+            s[0] += v.x; q[0] = fmaf(v.x, v.x, q[0]); s[1] += v.y; q[1] = fmaf(v.y, v.y, q[1]);
+            s[2] += v.z; q[2] = fmaf(v.z, v.z, q[2]); s[3] += v.w; q[3] = fmaf(v.w, v.w, q[3]);
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        __syncthreads();
+        sh[threadIdx.x * 2] = s[k];
+        sh[threadIdx.x * 2 + 1] = q[k];
+        __syncthreads();
+        if (tr == 0 && c4 < cg) {
+            double ds = 0, dq = 0;
+            for (int t = 0; t < tpr; ++t) { ds += sh[(t * cg + c4) * 2]; dq += sh[(t * cg + c4) * 2 + 1]; }
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2] = ds;
+            partial[((size_t)blockIdx.x * C + c4 * 4 + k) * 2 + 1] = dq;
+        }
+    }
+}
+
 // The network input [img (Cimg) | nmlF (3) | nmlB (3) | 0...] at H x W from an NCHW image and NCHW normal maps at (Hn x Wn)
 // - bilinear align_corners=True if the sizes differ (PIFuNetwNML.py:84-92, PIFuMRNet.py:99-103) - written DIRECTLY in the form
 // the first convolution's LDS-DMA reads: border-padded (zeros, or mirrored pixels for the normal nets' ReflectionPad) NHWC
@@ -1417,9 +1513,28 @@ Tensor conv_block(EncState &S, const std::string &p, Tensor x, int cout)
     return out;
 }
 
+// partial rows of a statistics-producing element-wise pass over P pixels (the geometry k_channel_stats would use)
+void attach_stats(EncState &S, Tensor &t, int *rows_per_block)
+{
+    const int P = (int)t.pixels();
+    // ~2 048 blocks: these passes also COMPUTE (16 taps per bicubic output), so they want more waves in flight than the pure
+    // reduction's 256 blocks; the finalize kernel takes any number of partial rows
+    int rows = (P + 2047) / 2048;
+    *rows_per_block = rows < 8 ? 8 : rows;
+    t.stat_nb = (P + *rows_per_block - 1) / *rows_per_block;
+    t.stat = reinterpret_cast<double *>(arena_take(S, (size_t)t.stat_nb * t.C * 2 * 2));
+}
+
 Tensor avg_pool(EncState &S, const Tensor &x)
 {
     Tensor o = new_tensor(S, x.H / 2, x.W / 2, x.C);
+    if (S.norm != 0 && S.fuse_stats) {      // the ConvBlock that follows normalises this tensor: leave its statistics behind
+        int rpb = 0;
+        attach_stats(S, o, &rpb);
+        hipLaunchKernelGGL(k_avgpool2_stats, dim3(o.stat_nb), dim3(stat_threads(x.C)), 0, S.cur->st, (const float *)x.p, x.ld, x.W, o.p, o.ld,
+                           x.C, o.H, o.W, rpb, o.stat);
+        return o;
+    }
     hipLaunchKernelGGL(k_avgpool2, dim3(nblk(o.pixels() * (x.C / 4), 256)), dim3(256), 0, S.cur->st, (const float *)x.p, x.ld, x.W, o.p, o.ld,
                        x.C, o.H, o.W);
     return o;
@@ -1455,6 +1570,13 @@ Tensor hourglass(EncState &S, const std::string &p, int level, const Tensor &x)
         low = low_chain();
     }
     Tensor out = new_tensor(S, x.H, x.W, x.C);
+    if (S.norm != 0 && S.fuse_stats) {      // (see avg_pool)
+        int rpb = 0;
+        attach_stats(S, out, &rpb);
+        hipLaunchKernelGGL(k_bicubic_up2_add_stats, dim3(out.stat_nb), dim3(stat_threads(x.C)), 0, S.cur->st, (const float *)low.p, low.ld,
+                           low.H, low.W, (const float *)up1.p, up1.ld, out.p, out.ld, x.C, rpb, out.stat);
+        return out;
+    }
     hipLaunchKernelGGL(k_bicubic_up2_add, dim3(nblk(out.pixels() * (x.C / 4), 256)), dim3(256), 0, S.cur->st, (const float *)low.p, low.ld,
                        low.H, low.W, (const float *)up1.p, up1.ld, out.p, out.ld, x.C);
     return out;
