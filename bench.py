@@ -431,6 +431,7 @@ def genmesh_multi(args, netMR, dev, data, synth, dist, rank, world, fence, log):
                 _lm = _lib_mod()
                 _lm.call('pifu_set_workspace_limit', netMR._ctx.h, 1)
                 _lm.call('pifu_set_workspace_limit', netMR._ctx.h, 0)
+                _lm.call('pifu_enc_clear', netMR._ctx.h)      # ... and its encoders' lane arenas + packed weights (~19 GB): no leg filters with it again
                 torch.cuda.empty_cache()
             net5, err = guarded('config 5 (building the smoother subject)',
                                 lambda: smoother_subject(args, dev, data, share=(0.25 / world) if one_gpu else None))

@@ -7,7 +7,7 @@ if len(sys.argv) > 2 and sys.argv[1] == '--report':
     import csv, collections
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r['Start_Timestamp']))
     def short(n): return n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
-    packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_input')]
+    packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_prepared')]
     back = int(os.environ.get('PACKS_BACK', '1'))          # 2 with `global`: from the normal nets' packed input on
     seq = rows[packs[-back]:]
     t0 = int(seq[0]['Start_Timestamp'])

@@ -13,7 +13,7 @@ def short(n):
     return n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
 
 
-packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_input')]
+packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_prepared')]
 seq = rows[packs[-3]:]                 # a pass packs three times: normal-net input, coarse hourglass input, fine input
 agg = defaultdict(lambda: [0, 0.0])
 for r in seq:

@@ -12,7 +12,7 @@ def short(n):
     return n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
 
 
-packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_input')]
+packs = [i for i, r in enumerate(rows) if short(r['Kernel_Name']).startswith('k_pack_prepared')]
 # a pass packs three times (normal-net input, coarse hourglass input, fine input)
 lo = packs[-3] if len(packs) >= 3 else 0
 seq = rows[lo:]

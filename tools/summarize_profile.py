@@ -33,9 +33,9 @@ gemm_rows = [r for r in rows if 'k_mlp_gemm' in r['Name']]
 mix = ''
 if gemm_rows:
     calls = sum(int(r['Calls']) for r in gemm_rows)
-    mix = (f'# k_mlp_gemm_tri launch mix of this trace: {calls} launches = (1 warm-up + 2 timed) passes over the 256^3 lattice in 8 '
-           f'batches x 7 layer launches (= 168, the headline mix, chunk 5000) + {calls - 168} launches of the set-up call '
-           f'(calibrate_occupancy_bias on a 64^3 lattice, pixel-table-free); no other leg of bench.py runs in this trace\n')
+    mix = (f'# k_mlp_gemm_tri launch mix of this trace: {calls} launches = (1 warm-up + 2 timed) passes over the 256^3 lattice, each 2 '
+           f'column-table launches + 9 batches (batch_rows 2 097 152) x 6 layer launches (= 168, the headline mix, chunk 5000) + {calls - 168} '
+           f'launches of the set-up call (calibrate_occupancy_bias on a 64^3 lattice, pixel-table-free); no other leg of bench.py runs in this trace\n')
 with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
     f.write(f'# rocprofv3 --kernel-trace --stats -- {command}   (MI355X, 1 GPU)\n')
     f.write(mix)
