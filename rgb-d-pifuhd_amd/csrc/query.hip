@@ -75,6 +75,13 @@ struct GemmArgs {
     const float *zf;      // [rows] depth feature per point row
     const int *colidx;    // [rows] column of the point row
     int qrel;             // pixel tables: colQ is a per-ROW table [rows][ldq] (row r starts from colQ[r]); colidx is not read
+    // k_mlp_gemm_tri<., ., 1> (an MLP without norm layers, the 128-wide layer in front of the Cout = 1 layer): the epilogue applies
+    // LeakyReLU, dots each row with the last layer's weights and writes sigmoid(dot + bias) * mask - Y is neither stored nor read back
+    const float *last_w;        // [128]
+    float last_bias;
+    const uint8_t *last_mask;   // per row (k_last_layer's), with last_mask_bit = 1, 2 or 0 (no mask)
+    int last_mask_bit;
+    float *last_out;            // [points of this batch], indexed chunk * g.chunk + local
     // per-K-step operand descriptors (k_mlp_gemm_split): everything that depends on the segment is resolved on the
     // host, so the kernel fetches one descriptor per step with scalar loads instead of a ~60-instruction select chain
     struct StepDesc {
@@ -207,7 +214,7 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
 // K step costs one more barrier here (the tile is overwritten in place once every wave has read its fragments), which the
 // two other resident blocks cover.  Same tiles, k order and statistics as k_mlp_gemm_buf: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int PRIO, int QREL = 0>
+template <int PRIO, int QREL = 0, int FUSE = 0>
 __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 {
     constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
@@ -333,6 +340,30 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
     int nvalid = chunk_len(a.g, chunk_id) - local0;
     nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
     float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
+    if (FUSE) {
+        // the Cout = 1 layer in this layer's epilogue (pointwise norm: nothing but LeakyReLU lies between them, and the 128
+        // columns of a row are all in this block): per lane the products of its two columns, per row 64 partial sums through
+        // LDS ([128 rows][65]: conflict-free), summed in a fixed order by one thread per row
+        constexpr int RS = 65;
+        const float b0 = a.bias[wn * 64 + j], b1 = a.bias[wn * 64 + 32 + j];
+        const float w0 = a.last_w[wn * 64 + j], w1 = a.last_w[wn * 64 + 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[(wm * 64 + rr) * RS + wn * 32 + j] = fmaf(leaky(acc00[r] + b0), w0, leaky(acc01[r] + b1) * w1);
+            red[(wm * 64 + 32 + rr) * RS + wn * 32 + j] = fmaf(leaky(acc10[r] + b0), w0, leaky(acc11[r] + b1) * w1);
+        }
+        __syncthreads();
+        if (tid < BM && tid < nvalid) {
+            float dot = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) dot += red[tid * RS + k];
+            float p = 1.f / (1.f + expf(-(dot + a.last_bias)));
+            if (a.last_mask_bit && !(a.last_mask[row0 + tid] & a.last_mask_bit)) p = 0.f;
+            a.last_out[(int64_t)chunk_id * a.g.chunk + local0 + tid] = p;
+        }
+        return;
+    }
     const __amdgpu_buffer_rsrc_t rY = buf_rsrc(a.Y + row0 * (size_t)a.ldy + col0);
     const unsigned ldy4 = (unsigned)a.ldy * 4u;
     const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;
@@ -1384,7 +1415,8 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     if (lab_launch_fp32_gemm(ctx, a, st)) return;
 #endif
     (void)ctx;
-    if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    if (a.last_out) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    else if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
 }
 
@@ -1398,6 +1430,19 @@ static inline int stat_halves(const pifu_ctx *ctx)
 #else
     (void)ctx;
     return 1;
+#endif
+}
+
+// An MLP without norm layers (MLP.py:37-41: the published pifuhd.pt): the layer in front of the Cout = 1 layer can take that layer
+// into its epilogue when its 128 outputs are one column tile, the last layer reads nothing else (no skip input), and the exact-fp32
+// kernel runs - the 128-wide activations (1 GB per 2 M-row batch) are then neither written nor read back by k_last_layer.
+static bool fuse_last_layer(const pifu_ctx *ctx, const Mlp &m, int i, const float *pred_out, int upto_layer)
+{
+#ifdef PIFU_LAB
+    return false;
+#else
+    return m.norm == PIFU_NORM_NONE && i == m.nlayers - 2 && upto_layer >= m.nlayers && pred_out != nullptr && ctx->precision == 0 &&
+           m.layer[i].cout == BN && m.layer[i].cout_pad == BN && m.layer[i + 1].cin_feat == 0 && m.layer[i + 1].cout == 1;
 #endif
 }
 
@@ -1448,6 +1493,10 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             const bool stats = (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN);
             a.partial = stats ? b.partial[i] : nullptr;
             a.ntm = ntm; a.ntn = l.cout_pad / BN; a.g = g;
+            if (fuse_last_layer(ctx, m, i, pred_out, upto_layer)) {
+                const MlpLayer &ll = m.layer[i + 1];
+                a.last_w = ll.w; a.last_bias = ll.host_bias0; a.last_mask = mask; a.last_mask_bit = mask_bit; a.last_out = pred_out;
+            }
             const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
             int rc2 = run_gemm(ctx, a, 2.0 * valid * l.cout * (double)(l.cin_prev + l.cin_feat), st);
             if (rc2) return rc2;
@@ -1461,7 +1510,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                                    );
             }
         } else {
-            if (!pred_out) continue;
+            if (!pred_out || fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer)) continue;      // (fused into the previous layer's epilogue)
             LastArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
@@ -1860,6 +1909,10 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                     a.colQ = T.Q[L]; a.ldq = T.ldq[L]; a.qoff = l.col_off; a.colwz = L == 0 ? l.wz : nullptr;
                     a.zf = pl.zf; a.colidx = pl.colidx;
                 }
+                if (!a.qrel && fuse_last_layer(ctx, m, i, pred_out, upto_layer)) {
+                    const MlpLayer &ll = m.layer[i + 1];
+                    a.last_w = ll.w_col; a.last_bias = ll.host_bias0; a.last_mask = pl.mask; a.last_mask_bit = mask_bit; a.last_out = pred_out;
+                }
                 int rc = run_gemm(ctx, a, 2.0 * valid * l.cout * (double)l.cin_col, st);
                 if (rc) return rc;
             }
@@ -1873,6 +1926,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
             }
         } else {
             if (!pred_out) continue;
+            if (fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer) && !(m.layer[i - 1].cin_feat && px)) continue;      // fused into the previous layer
             LastArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
