@@ -228,6 +228,7 @@ class PIFuNetwNML(BasePIFuNet):
         self.netB = 'netB' if getattr(opt, 'use_back_normal', False) else None
         self._last_n = 0
         self._dirty, self._pushed_code = True, None
+        self._enc_dirty, self._enc_keep = True, []      # the encoder tensors changed since they were registered (load_state_dict does)
 
     @property
     def _ctx(self):
@@ -246,7 +247,7 @@ class PIFuNetwNML(BasePIFuNet):
         self._sd = {k[len(_prefix):]: state_dict[k].detach().to(self.device, torch.float32)
                     if state_dict[k].dtype.is_floating_point else state_dict[k]
                     for k in spec if k in state_dict}
-        self._dirty = True
+        self._dirty = self._enc_dirty = True
 
     def state_dict(self):
         """Flat dict keyed like the reference module's `state_dict()` (no 'netG.' prefix)."""
@@ -271,7 +272,7 @@ class PIFuNetwNML(BasePIFuNet):
                     not_init.add(k[len(part):].split('.')[0])
             print(label, sorted(not_init))
         self._sd = mine
-        self._dirty = True
+        self._dirty = self._enc_dirty = True
 
     def _push_weights(self):
         o = self.opt
@@ -280,7 +281,11 @@ class PIFuNetwNML(BasePIFuNet):
         ctx = self._ctx_obj
         _push_mlp(ctx, _lib.LEVEL_COARSE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), int(o.merge_layer), code)
         _lib.call('pifu_set_depth_normalizer', ctx.h, float(o.loadSize // 2), float(o.z_size))
-        self._enc_keep = _push_encoder_params(ctx, self._sd, '')      # borrowed by the library until the next push
+        # the encoders' tensors go across only when they changed (an explicit load): a re-push for the MLPs' sake - train / eval,
+        # a bias shifted by synth.calibrate_occupancy_bias - must not make the library drop and repack 1.5 GB of convolution weights
+        if self._enc_dirty:
+            self._enc_keep = _push_encoder_params(ctx, self._sd, '')      # borrowed by the library until the next push
+            self._enc_dirty = False
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):
@@ -477,6 +482,7 @@ class PIFuMRNet(BasePIFuNet):
         self.normx = None
         self.training = True          # a freshly constructed module is in train mode (SURVEY C-2)
         self._dirty, self._pushed_code = True, None
+        self._enc_dirty, self._enc_keep = True, []
 
     @property
     def _ctx(self):
@@ -502,7 +508,7 @@ class PIFuMRNet(BasePIFuNet):
         synth.mlp_keys('mlp', self.opt.mlp_dim, self.opt.mlp_res_layers, self.opt.mlp_norm, own)
         self._sd = {k: state_dict[k].detach().to(self.device, torch.float32)
                     if state_dict[k].dtype.is_floating_point else state_dict[k] for k in own if k in state_dict}
-        self._dirty = True
+        self._dirty = self._enc_dirty = True
 
     def state_dict(self):
         """Flat dict with the reference's key scheme: own tensors + the coarse net's under 'netG.'."""
@@ -518,7 +524,9 @@ class PIFuMRNet(BasePIFuNet):
         self.netG._sync_weights()                               # the fine MLP is defined against the coarse one
         ctx = self.netG._ctx_obj
         _push_mlp(ctx, _lib.LEVEL_FINE, self._sd, 'mlp', list(o.mlp_dim), list(o.mlp_res_layers), -1, code)
-        self._enc_keep = _push_encoder_params(ctx, self._sd, 'fine.')
+        if self._enc_dirty:
+            self._enc_keep = _push_encoder_params(ctx, self._sd, 'fine.')
+            self._enc_dirty = False
         self._dirty, self._pushed_code = False, code
 
     def _sync_weights(self):

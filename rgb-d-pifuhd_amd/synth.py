@@ -338,7 +338,9 @@ def craft_body_mlps(sd, opt_coarse, opt_fine, feat_coarse, seed: int = 0, sharpn
     last = len(of.mlp_dim) - 2
     gen = torch.Generator().manual_seed((fnv1a64('craft_body_tail') ^ seed) & 0x7FFFFFFFFFFFFFFF)
     Wl = sd[f'{nf}.filters.{last}.weight']
-    Wl.copy_(torch.randn(Wl.shape, generator=gen) * tail_std)             # what the other channels add: a sub-voxel ripple
+    # what the other channels add: a sub-voxel ripple (without norm layers their activations are several times larger than under
+    # GroupNorm - the same weights would raise specks of a few faces beside the body - so the tail is scaled down there)
+    Wl.copy_(torch.randn(Wl.shape, generator=gen) * (tail_std if gn else 0.3 * tail_std))
     if gn:
         Wl[0, :of.mlp_dim[3] // 32, 0] = 0.0                              # (the ballast pair of the last hidden layer)
     Wl[0, 0, 0], Wl[0, 1, 0] = sharpness / 1.01 ** 3, -sharpness / 1.01 ** 3
