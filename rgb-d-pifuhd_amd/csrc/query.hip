@@ -214,7 +214,7 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
 // K step costs one more barrier here (the tile is overwritten in place once every wave has read its fragments), which the
 // two other resident blocks cover.  Same tiles, k order and statistics as k_mlp_gemm_buf: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int PRIO, int QREL = 0, int FUSE = 0>
+template <int PRIO, int QREL = 0, int FUSE = 0>      // FUSE: 0 bias + store + statistics, 1 the Cout = 1 layer in the epilogue, 2 bias + store only
 __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
 {
     constexpr int TBK = 32, LD = TBK + 4, TILE = BM * LD, NS = TBK / 8;
@@ -368,6 +368,17 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
     const unsigned ldy4 = (unsigned)a.ldy * 4u;
     const unsigned voY = (unsigned)(wm * 64 + 4 * h) * ldy4 + (unsigned)(wn * 64 + j) * 4u;
     const float bias0 = a.bias[col0 + wn * 64 + j], bias1 = a.bias[col0 + wn * 64 + 32 + j];
+    if (FUSE == 2) {      // no statistics wanted (pointwise norm, table / start-value products): bias + raw store, nothing else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ro = (unsigned)((r & 3) + 8 * (r >> 2)) * ldy4;
+            buf_store1(acc00[r] + bias0, rY, voY, ro);
+            buf_store1(acc10[r] + bias0, rY, voY, ro + 32u * ldy4);
+            buf_store1(acc01[r] + bias1, rY, voY, ro + 128u);
+            buf_store1(acc11[r] + bias1, rY, voY, ro + 32u * ldy4 + 128u);
+        }
+        return;
+    }
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     if (nvalid >= BM) {
         BUF_EPI(acc00, 0, 0, bias0, s0, q0, false) BUF_EPI(acc10, 1, 0, bias0, s0, q0, false)
@@ -1415,9 +1426,12 @@ static void launch_fp32_gemm(pifu_ctx *ctx, const GemmArgs &a, hipStream_t st)
     if (lab_launch_fp32_gemm(ctx, a, st)) return;
 #endif
     (void)ctx;
-    if (a.last_out) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0>), dim3((unsigned)round_up(a.ntm, 8) * a.ntn), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)round_up(a.ntm, 8) * a.ntn);
+    if (a.last_out) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0, 1>), grid, dim3(256), 0, st, a);
+    else if (!a.partial && a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1, 2>), grid, dim3(256), 0, st, a);
+    else if (!a.partial) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0, 2>), grid, dim3(256), 0, st, a);
+    else if (a.qrel) hipLaunchKernelGGL((k_mlp_gemm_tri<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_gemm_tri<0, 0>), grid, dim3(256), 0, st, a);
 }
 
 static int run_gemm(pifu_ctx *ctx, GemmArgs &a, double flops, hipStream_t st);
