@@ -82,6 +82,12 @@ struct GemmArgs {
     const uint8_t *last_mask;   // per row (k_last_layer's), with last_mask_bit = 1, 2 or 0 (no mask)
     int last_mask_bit;
     float *last_out;            // [points of this batch], indexed chunk * g.chunk + local
+    // the last layer's skip input under column sharing / pixel tables (coarse level): logit += last_colQ[col or row][last_qoff] + last_wz0 * zf
+    const float *last_colQ;     // or null
+    int last_ldq, last_qoff, last_qrel;
+    float last_wz0;
+    const float *last_zf;
+    const int *last_colidx;
     // per-K-step operand descriptors (k_mlp_gemm_split): everything that depends on the segment is resolved on the
     // host, so the kernel fetches one descriptor per step with scalar loads instead of a ~60-instruction select chain
     struct StepDesc {
@@ -358,6 +364,10 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
             float dot = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 64; ++k) dot += red[tid * RS + k];
+            if (a.last_colQ) {
+                const size_t qrow = a.last_qrel ? row0 + tid : (size_t)a.last_colidx[row0 + tid];
+                dot += fmaf(a.last_wz0, a.last_zf[row0 + tid], a.last_colQ[qrow * a.last_ldq + a.last_qoff]);
+            }
             float p = 1.f / (1.f + expf(-(dot + a.last_bias)));
             if (a.last_mask_bit && !(a.last_mask[row0 + tid] & a.last_mask_bit)) p = 0.f;
             a.last_out[(int64_t)chunk_id * a.g.chunk + local0 + tid] = p;
@@ -1450,13 +1460,16 @@ static inline int stat_halves(const pifu_ctx *ctx)
 // An MLP without norm layers (MLP.py:37-41: the published pifuhd.pt): the layer in front of the Cout = 1 layer can take that layer
 // into its epilogue when its 128 outputs are one column tile, the last layer reads nothing else (no skip input), and the exact-fp32
 // kernel runs - the 128-wide activations (1 GB per 2 M-row batch) are then neither written nor read back by k_last_layer.
-static bool fuse_last_layer(const pifu_ctx *ctx, const Mlp &m, int i, const float *pred_out, int upto_layer)
+static bool fuse_last_layer(const pifu_ctx *ctx, const Mlp &m, int i, const float *pred_out, int upto_layer, bool skip_as_start_value = false)
 {
 #ifdef PIFU_LAB
     return false;
 #else
-    return m.norm == PIFU_NORM_NONE && i == m.nlayers - 2 && upto_layer >= m.nlayers && pred_out != nullptr && ctx->precision == 0 &&
-           m.layer[i].cout == BN && m.layer[i].cout_pad == BN && m.layer[i + 1].cin_feat == 0 && m.layer[i + 1].cout == 1;
+    // (a last layer with a skip input is taken in only where that input arrives as a per-column / per-row start value:
+    // launch_level_col; the per-point path would have to read the feature rows again)
+    return m.norm == PIFU_NORM_NONE && i >= 0 && i == m.nlayers - 2 && upto_layer >= m.nlayers && pred_out != nullptr && ctx->precision == 0 &&
+           m.layer[i].cout == BN && m.layer[i].cout_pad == BN && (m.layer[i + 1].cin_feat == 0 || skip_as_start_value) &&
+           m.layer[i + 1].cout == 1;
 #endif
 }
 
@@ -1923,9 +1936,16 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                     a.colQ = T.Q[L]; a.ldq = T.ldq[L]; a.qoff = l.col_off; a.colwz = L == 0 ? l.wz : nullptr;
                     a.zf = pl.zf; a.colidx = pl.colidx;
                 }
-                if (!a.qrel && fuse_last_layer(ctx, m, i, pred_out, upto_layer)) {
+                if (!a.qrel && fuse_last_layer(ctx, m, i, pred_out, upto_layer, true)) {
                     const MlpLayer &ll = m.layer[i + 1];
                     a.last_w = ll.w_col; a.last_bias = ll.host_bias0; a.last_mask = pl.mask; a.last_mask_bit = mask_bit; a.last_out = pred_out;
+                    if (ll.cin_feat && px) {
+                        a.last_colQ = pl.S; a.last_ldq = pl.ldS; a.last_qoff = ll.col_off - px->g1; a.last_qrel = 1;
+                        a.last_wz0 = L == 0 ? ll.host_wz0 : 0.f; a.last_zf = pl.zf;
+                    } else if (ll.cin_feat) {
+                        a.last_colQ = T.Q[L]; a.last_ldq = T.ldq[L]; a.last_qoff = ll.col_off; a.last_qrel = 0;
+                        a.last_wz0 = L == 0 ? ll.host_wz0 : 0.f; a.last_zf = pl.zf; a.last_colidx = pl.colidx;
+                    }
                 }
                 int rc = run_gemm(ctx, a, 2.0 * valid * l.cout * (double)l.cin_col, st);
                 if (rc) return rc;
@@ -1940,7 +1960,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
             }
         } else {
             if (!pred_out) continue;
-            if (fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer) && !(m.layer[i - 1].cin_feat && px)) continue;      // fused into the previous layer
+            if (fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer, true) && !(m.layer[i - 1].cin_feat && px)) continue;      // fused into the previous layer
             LastArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
