@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 3) void k_mlp_gemm_tri(const GemmArgs a)
     int nvalid = chunk_len(a.g, chunk_id) - local0;
     nvalid = nvalid < 0 ? 0 : (nvalid > BM ? BM : nvalid);
     float *red = lds;   // [2 (sum|sq)][2 (wm)][BN]; safe: every wave passed the loop's final barrier
-    if (FUSE) {
+    if (FUSE == 1) {
         // the Cout = 1 layer in this layer's epilogue (pointwise norm: nothing but LeakyReLU lies between them, and the 128
         // columns of a row are all in this block): per lane the products of its two columns, per row 64 partial sums through
         // LDS ([128 rows][65]: conflict-free), summed in a fixed order by one thread per row
