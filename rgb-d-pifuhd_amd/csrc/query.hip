@@ -2174,13 +2174,10 @@ int pifu_query_impl(pifu_ctx *ctx, int src_mode, const float *points, int64_t n,
                 // column segments of this batch (ordered compaction of the segment starts)
                 const WalkPlan &w = pl.wk;
                 const int ntiles = (int)((rows + SEG_TILE - 1) / SEG_TILE);
-                // rows of a column more than 24 lattice steps apart in depth start a segment of their own (walk.inc); the
-                // projected z of a lattice point is its grid coordinate, so a step is 2 / res[2] of it, scaled like the feature
-                const float zgap = 24.f * (2.f / (float)res[2]) * fabsf(ctx->z_mul / ctx->z_div);
-                hipLaunchKernelGGL(k_seg_count, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, (const float *)pl.zf, zgap, g, rows, w.tile_cnt);
+                hipLaunchKernelGGL(k_seg_count, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, g, rows, w.tile_cnt);
                 hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, (const int *)w.tile_cnt, ntiles, w.tile_off, w.nseg_dev,
                                    w.chunk_seg0, g.nchunks);
-                hipLaunchKernelGGL(k_seg_scatter, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, (const float *)pl.zf, zgap, g, rows,
+                hipLaunchKernelGGL(k_seg_scatter, dim3(ntiles), dim3(256), 0, st, (const int *)pl.colidx, g, rows,
                                    (const int *)w.tile_off, w.seg_row0, w.chunk_seg0, w.maxseg);
                 int64_t nseg = 0;
                 if (src_mode == 1) {        // dense range: the count is known on the host
