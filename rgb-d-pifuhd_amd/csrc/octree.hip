@@ -124,7 +124,7 @@ __global__ void k_oct_fill(double *sdf, uint8_t *notproc, int R, int reso, int n
         if (j % reso == 0 && q - 1 >= 0 && q - 1 <= nc - 1) cj[nj++] = q - 1;
     }
     if (ni == 0 || nj == 0) return;
-    const int k1 = min(k0 + FILL_RUN, R);
+    int k1 = min(k0 + FILL_RUN, R);
     const int qlo = max(k0 / reso - 1, 0), qhi = min((k1 - 1) / reso, nc - 1);      // cells along k any voxel of the run can belong to
     if (qhi < qlo) return;
     bool any = false;
@@ -135,6 +135,18 @@ __global__ void k_oct_fill(double *sdf, uint8_t *notproc, int R, int reso, int n
         }
     if (!any) return;
     const int64_t base = ((int64_t)i * R + j) * R;
+    // most runs of a filled region lie strictly inside one cell row (i and j off the cell faces): after the run's first voxel,
+    // which may sit on a face along k, the rest share the single cell k / reso - one look-up, then plain stores
+    if (ni == 1 && nj == 1 && reso >= FILL_RUN && k1 - k0 == FILL_RUN && (k0 + 1) / reso == (k1 - 1) / reso && (k0 + 1) % reso != 0 &&
+        (k0 + 1) / reso <= nc - 1) {
+        const int64_t cell = ((int64_t)ci[0] * nc + cj[0]) * nc + (k0 + 1) / reso;
+        if (cell_skip[cell]) {
+            const double m = cell_mean[cell];
+#pragma unroll
+            for (int k = 1; k < FILL_RUN; ++k) { sdf[base + k0 + k] = m; notproc[base + k0 + k] = 0; }
+        }
+        k1 = k0 + 1;          // only the first voxel is left for the general path
+    }
     for (int k = k0; k < k1; ++k) {
         int ck[2], nk = 0;
         const int q = k / reso;
