@@ -126,3 +126,40 @@ def test_group_norm_is_never_regrouped():
     a = _eval(netMR, res, 0, n, 5000)
     b = _eval(netMR, res, 0, n, 4096)
     assert float((a - b).abs().max()) > 1e-6
+
+
+def test_pointwise_octree_composition_vs_oracle(observed):
+    """The multi-level octree of `reconstruction()` in the un-normalised configuration - every level's index list evaluated in
+    the library's own groups, the Cout = 1 layers in the GEMM epilogues, the depth walk - against the same composition on the CPU
+    oracle in 5 000-point calls (`mesh_util.py:124-187` + `PIFuMRNet.query`): R = 128, two levels, the same number of points per
+    level, the float64 SDF within the north star's 1e-4, marching cubes on the device SDF bit-identical to the serial oracle's."""
+    import os
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import mesh_util, synth
+    netG, netMR, sd, oc, of = _build('no', mlp_std=0.10)
+    calib_t = calib_tensor()
+    shift = synth.calibrate_occupancy_bias(netMR, calib_t, sd, 0.3, resolution=32)      # the 0.5 level inside the volume
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    _, cinv = mesh_util.calib_pair(calib_t)
+
+    def field(pts):
+        with torch.no_grad():
+            return ref.query(torch.from_numpy(pts.astype(np.float32))[None], calib_t)[0, 0].numpy()
+    stats = []
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        want = O.eval_grid_octree(128, cinv, field, 5000, init_resolution=64, stats=stats)
+    finally:
+        torch.set_num_threads(threads)
+    sdf, n_eval = mesh_util.eval_grid_device(netMR, calib_t, 128, 5000, True, init_resolution=64)
+    got = sdf.cpu().numpy()
+    err = float(np.abs(got - want).max())
+    observed('pointwise_octree_128', gpu_vs_oracle_sdf=err, points=int(n_eval), bias_shift=shift)
+    assert len(stats) == 2 and all(n > 0 for _, n in stats) and n_eval == sum(n for _, n in stats)
+    assert err < 1e-4
+    gv, gf = mesh_util.marching_cubes_device(netMR._ctx, sdf, 0.5)
+    ov, of_ = O.marching_cubes_lewiner(got, 0.5)
+    assert len(gv) > 1000 and np.array_equal(gf.cpu().numpy(), of_)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), ov.view(np.uint32))
