@@ -55,12 +55,27 @@ def launch_ranks(n):
     the command the driver itself uses) before torch or the GPU is touched in this process, let it write to this process's
     stdout / stderr, and hand back its return code.  The elastic agent ends the other ranks when one of them fails, so a
     failed rank cannot leave the rest waiting in a collective."""
+    import random
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    # a free port BELOW the kernel's ephemeral range (32768+): one probed with bind(0) can be handed out again - as the source
+    # port of somebody's outgoing connection - between the probe and the launcher's own bind (seen once: EADDRINUSE in the
+    # rendezvous TCPStore); ports in 15000 - 29999 are only ever taken by listeners, which the probe sees
+    port = None
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e3))
+    for _ in range(64):
+        cand = rng.randrange(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', cand))
+            port = cand
+            break
+        except OSError:
+            continue
+        finally:
+            s.close()
+    if port is None:
+        raise SystemExit('no free rendezvous port found in 15000-29999')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, cwd=ROOT).returncode
