@@ -74,3 +74,24 @@ def calib_variant(tag):
     else:
         raise KeyError(tag)
     return c[None]
+
+
+def free_port():
+    """A free TCP port on 127.0.0.1 BELOW the kernel's ephemeral range: a port probed with bind(0) can be handed out again - as the
+    source port of an outgoing connection - before the rendezvous store binds it (seen once on the GPU box: EADDRINUSE)."""
+    import os
+    import random
+    import socket
+    import time
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e3))
+    for _ in range(64):
+        cand = rng.randrange(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(('127.0.0.1', cand))
+            return cand
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError('no free port in 15000-29999')

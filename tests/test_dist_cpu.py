@@ -27,11 +27,8 @@ def test_shard_chunks_cover_and_align():
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from helpers import free_port
+    return free_port()
 
 
 def _worker(rank, ws, port, total, chunk, q):

@@ -61,7 +61,7 @@ def test_pointwise_mlp_sharded_matches_single_process(tmp_path):
     """Two ranks (gloo, one GPU) in the pifuhd.pt configuration (`mlp_norm='no'`): dense lattice in raw Z-slabs, octree levels
     in 16 384-row groups, gen_mesh end to end - every rank holds the single-process result bit for bit."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     ctx = mp.get_context('spawn')
     procs = [ctx.Process(target=_pointwise_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
     for p in procs:
@@ -134,7 +134,7 @@ def test_gen_mesh_sharded_world2_matches_single_process(tmp_path, ws):
     """Two and three ranks (three: a rank beyond the two that run the dealt-out encoders only receives their maps; the colour
     rounds deal 50 000-vertex calls to ranks that may end up without one)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     ctx = mp.get_context('spawn')
     procs = [ctx.Process(target=_worker, args=(r, ws, port, str(tmp_path))) for r in range(ws)]
     for p in procs:
@@ -237,7 +237,7 @@ def test_rccl_transport_single_rank(tmp_path):
     """The `nccl` (RCCL) branch of the sharded path, on the one GPU this box has: process group of one rank, every
     collective of the path executed (all_gather_into_tensor of the field and of the colours, all_reduce, barrier), results
     identical to the collective-free run.  No scaling claim - only that the transport initialises, runs and shuts down."""
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     ctx = mp.get_context('spawn')
     p = ctx.Process(target=_rccl_worker, args=(port, str(tmp_path)))
     p.start()
@@ -252,7 +252,7 @@ def test_bench_dist_selftest_under_torchrun(tmp_path):
     N = 1 and --dist-selftest so that the process group (backend nccl) is created and the N > 1 code path runs."""
     import json
     import subprocess
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), 'bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--res', '64',
            '--genmesh-res', '64', '--batch-rows', '262144', '--dist-selftest', '--no-cpu-baseline', '--no-split-precision',
@@ -311,7 +311,7 @@ def test_slab_marching_cubes_world3_matches_the_replicated_run(tmp_path):
     """One axis-0 slab per rank, three ranks sharing the GPU over gloo: every rank must end with the vertices and faces
     of the single-process marching cubes, bit for bit - also when a rank is left without a cell layer (volumes with 2
     and 1 layers) - and skimage's exceptions must be raised on all ranks."""
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     mpctx = mp.get_context('spawn')
     procs = [mpctx.Process(target=_mc_worker, args=(r, 3, port, str(tmp_path))) for r in range(3)]
     for p in procs:
@@ -344,7 +344,7 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     not a number."""
     import json
     import subprocess
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     tail = ['--gpus', '2', '--steps', '1', '--warmup', '1', '--res', '64', '--genmesh-res', '64', '--config5-res', '128',
             '--batch-rows', '262144', '--no-split-precision', '--no-lean-pass', '--no-canonical']
     if launcher == 'torchrun':
@@ -467,7 +467,7 @@ def _worker_1024(rank, ws, port, outdir):
 @pytest.mark.timeout(1100)
 def test_gen_mesh_1024_sharded_world2_with_slab_marching_cubes(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port; port = free_port()
     mpctx = mp.get_context('spawn')
     procs = [mpctx.Process(target=_worker_1024, args=(r, 2, port, str(tmp_path))) for r in range(2)]
     for p in procs:
