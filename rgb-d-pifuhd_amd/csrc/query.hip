@@ -1495,6 +1495,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
         feat[1] = make_prev_seg(ctx, mc, pl.lv[0], mc.merge_layer);      // phi = act(norm(coarse layer merge))
         nfeat = 2;
     }
+    bool fused_last = false;      // the Cout = 1 layer went into the previous layer's epilogue (fuse_last_layer)
     for (int i = 0; i < m.nlayers && i < upto_layer; ++i) {
         const MlpLayer &l = m.layer[i];
         Seg segs[3];
@@ -1523,6 +1524,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
             if (fuse_last_layer(ctx, m, i, pred_out, upto_layer)) {
                 const MlpLayer &ll = m.layer[i + 1];
                 a.last_w = ll.w; a.last_bias = ll.host_bias0; a.last_mask = mask; a.last_mask_bit = mask_bit; a.last_out = pred_out;
+                fused_last = true;
             }
             const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
             int rc2 = run_gemm(ctx, a, 2.0 * valid * l.cout * (double)(l.cin_prev + l.cin_feat), st);
@@ -1537,7 +1539,7 @@ static int launch_level(pifu_ctx *ctx, int L, const Plan &pl, const ChunkGeom &g
                                    );
             }
         } else {
-            if (!pred_out || fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer)) continue;      // (fused into the previous layer's epilogue)
+            if (!pred_out || fused_last) continue;      // (fused: the previous layer's epilogue wrote the prediction)
             LastArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;
@@ -1831,6 +1833,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
     const int ntm = (int)(rows / BM);
     const bool stats = (m.norm == PIFU_NORM_GROUP || m.norm == PIFU_NORM_BATCH_TRAIN);
     const double valid = (double)(g.nchunks - 1) * g.chunk + g.last_len;
+    bool fused_last = false;      // the Cout = 1 layer went into the previous layer's epilogue (fuse_last_layer)
     for (int i = 0; i < m.nlayers && i < upto_layer; ++i) {
         const MlpLayer &l = m.layer[i];
         Seg segs[3];
@@ -1939,6 +1942,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
                 if (!a.qrel && fuse_last_layer(ctx, m, i, pred_out, upto_layer, true)) {
                     const MlpLayer &ll = m.layer[i + 1];
                     a.last_w = ll.w_col; a.last_bias = ll.host_bias0; a.last_mask = pl.mask; a.last_mask_bit = mask_bit; a.last_out = pred_out;
+                    fused_last = true;
                     if (ll.cin_feat && px) {
                         a.last_colQ = pl.S; a.last_ldq = pl.ldS; a.last_qoff = ll.col_off - px->g1; a.last_qrel = 1;
                         a.last_wz0 = L == 0 ? ll.host_wz0 : 0.f; a.last_zf = pl.zf;
@@ -1960,7 +1964,7 @@ static int launch_level_col(pifu_ctx *ctx, int L, const Plan &pl, const ColTable
             }
         } else {
             if (!pred_out) continue;
-            if (fuse_last_layer(ctx, m, i - 1, pred_out, upto_layer, true) && !(m.layer[i - 1].cin_feat && px)) continue;      // fused into the previous layer
+            if (fused_last) continue;      // fused: the previous layer's epilogue wrote the prediction
             LastArgs a{};
             for (int s = 0; s < ns; ++s) a.seg[s] = segs[s];
             a.nseg = ns;

@@ -81,6 +81,44 @@ def test_pointwise_regrouping_is_the_reference_field(observed, flags_name):
     assert np.array_equal(got == 0, want == 0) and err < 1e-4
 
 
+@pytest.mark.parametrize('mlp_norm', ['no', 'group'])
+def test_other_mlp_shapes_are_the_reference_field(observed, mlp_norm):
+    """MLP shapes other than the published ones (`options.py:96-108` are options, not constants): a three-layer coarse MLP
+    [257, 512, 128, 1] merging after its layer 1 and a fine MLP [144, 256, 128, 128, 1].  Without norms the 128-wide layer in front
+    of the Cout = 1 layer takes that layer into its epilogue from layer 1 of a three-layer MLP; with GroupNorm nothing is fused."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, config, mesh_util, nets, synth
+    oc = config.coarse_opt(mlp_norm=mlp_norm, mlp_dim=[257, 512, 128, 1], mlp_res_layers=[1], merge_layer=1)
+    of = config.fine_opt(oc, mlp_dim=[144, 256, 128, 128, 1], mlp_res_layers=[1, 2])
+    spec = {}
+    synth.mlp_keys('netG.mlp', oc.mlp_dim, oc.mlp_res_layers, oc.mlp_norm, spec)
+    synth.mlp_keys('mlp', of.mlp_dim, of.mlp_res_layers, of.mlp_norm, spec)
+    sd = synth.name_seeded_state_dict(spec, seed=11, mlp_std=0.10 if mlp_norm == 'no' else 0.16, perturb=True)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    fc, ff = seeded_features(7)
+    netG.set_features(fc)
+    netMR.set_features(ff)
+    res = (24, 32, 48)
+    n = res[0] * res[1] * res[2]
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = fc, ff
+    calib = calib_tensor()
+    _, calib_inv = mesh_util.calib_pair(calib)
+    want = []
+    with torch.no_grad():
+        for s in range(0, n, 5000):
+            flat = np.arange(s, min(s + 5000, n), dtype=np.int64)
+            pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, flat).astype(np.float32))[None]
+            want.append(ref.query(pts, calib)[0, 0].numpy())
+    want = np.concatenate(want)
+    for name, flags in (('default', 0), ('canonical', _lib.Q_NO_COLUMN_SHARING)):
+        got = _eval(netMR, res, 0, n, 5000, flags | _lib.Q_FULL_COARSE).cpu().numpy()
+        err = float(np.abs(got - want).max())
+        observed(f'other_mlp_shapes[{mlp_norm},{name}]', gpu_vs_oracle=err, field_std=float(want[want > 0].std()))
+        assert np.array_equal(got == 0, want == 0) and err < 1e-4
+    assert want[want > 0].std() > 0.01
+
+
 @pytest.mark.parametrize('ws', [2, 3, 8])
 def test_pointwise_slab_split_is_bit_identical(ws):
     """What `dist.sharded_eval` does with N ranks, rank by rank in one process: every rank's share - whole groups of the

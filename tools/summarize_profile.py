@@ -39,9 +39,14 @@ if gemm_rows:
 with open(f'profiles/{tag}_kernel_stats.csv', 'w') as f:
     f.write(f'# rocprofv3 --kernel-trace --stats -- {command}   (MI355X, 1 GPU)\n')
     f.write(mix)
+    if len(gemm_rows) > 1:
+        f.write('# k_mlp_gemm_tri appears once per template instantiation: the larger row is the one with the statistics epilogue (layer launches under '
+                'GroupNorm), the smaller one stores only (2 column-table launches per pass + the depth walk\'s table launch per batch + set-up)\n')
     f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
     for r in rows[:16]:
-        f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+        full = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        name = full[:60].replace(', ', '/').replace(',', '/') if full.startswith('k_mlp_gemm') else short(r['Name'])      # the GEMM's instantiations stay apart: <PRIO, QREL, FUSE>
+        f.write(f"{name},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
 
 
 def pmc(dirname):
