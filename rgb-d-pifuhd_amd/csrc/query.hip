@@ -1466,7 +1466,10 @@ static bool fuse_last_layer(const pifu_ctx *ctx, const Mlp &m, int i, const floa
     return false;
 #else
     // (a last layer with a skip input is taken in only where that input arrives as a per-column / per-row start value:
-    // launch_level_col; the per-point path would have to read the feature rows again)
+    // launch_level_col; the per-point path would have to read the feature rows again).  The fused epilogue does not store the
+    // layer's own output: not for the coarse layer whose output is phi, the fine level's input (MLP.py:61-62 with a merge
+    // layer right in front of the last one - no published configuration, tests/test_gpu_pointwise.py has one)
+    if (&m == &ctx->mlp[0] && i == m.merge_layer) return false;
     return m.norm == PIFU_NORM_NONE && i >= 0 && i == m.nlayers - 2 && upto_layer >= m.nlayers && pred_out != nullptr && ctx->precision == 0 &&
            m.layer[i].cout == BN && m.layer[i].cout_pad == BN && (m.layer[i + 1].cin_feat == 0 || skip_as_start_value) &&
            m.layer[i + 1].cout == 1;

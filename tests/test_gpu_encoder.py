@@ -358,3 +358,67 @@ def test_deferred_hourglass_is_joined_by_every_stream():
         del junk
         assert torch.equal(netG.im_feat_list[0], want_feat)
         assert torch.equal(pred, want_pred)
+
+
+@pytest.mark.parametrize('front,back', [(True, False), (False, True), (False, False)])
+def test_normal_map_option_variants(front, back, observed):
+    """`use_front_normal` / `use_back_normal` (`options.py:162-163`, read from the checkpoint's opt: `PIFuNetwNML.py:33-36,64-67`,
+    `PIFuMRNet.py:31-34,92-95`) switch a normal net and three input channels of both filters off.  Tiny sizes (64 / 128 px),
+    both levels against the CPU oracle."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import config, nets, synth
+    oc = config.coarse_opt(use_front_normal=front, use_back_normal=back)
+    of = config.fine_opt(oc, loadSizeBig=128)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=0.16, perturb=True)
+    assert ('netG.netF.model.1.weight' in sd) == front and ('netG.netB.model.1.weight' in sd) == back
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    img64, img128 = synth.synthetic_image(64, 3, seed=2), synth.synthetic_image(128, 3, seed=3)
+    netMR.filter_global(img64)
+    netMR.filter_local(img128[:, None])
+    assert (netG.nmlF is not None) == front and (netG.nmlB is not None) == back
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    with torch.no_grad():
+        fc = ref.filter_global(img64).numpy()
+        ff = ref.filter_local(img128).numpy()
+    ec, ef = _rel(netG.im_feat_list[0].cpu().numpy(), fc), _rel(netMR.im_feat_list[0].cpu().numpy(), ff)
+    observed(f'normal_map_options[front={front},back={back}]', coarse_rel=ec, fine_rel=ef)
+    assert ec < 2e-4 and ef < 2e-4
+    # and the occupancy through both levels
+    calib = torch.eye(4)[None]; calib[0, 1, 1] = -1
+    pts = (torch.rand(1, 3, 3000, generator=torch.Generator().manual_seed(5)) * 2 - 1)
+    netMR.query(pts, calib)
+    with torch.no_grad():
+        want = ref.query(pts, calib)[0, 0].numpy()
+    got = netMR.get_preds()[0, 0].cpu().numpy()
+    assert float(np.abs(got - want).max()) < 1e-4
+
+
+@pytest.mark.parametrize('norm', ['batch', 'group'])
+def test_other_filter_shapes(norm, observed):
+    """Filter shapes other than the published ones (`options.py:86-93` are options): two stacks of depth-3 hourglasses with 128
+    channels for the coarse level, 32 channels for the fine one; MLP input widths follow (129 / 288).  Tiny images, encoders and
+    occupancy against the CPU oracle."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import config, nets, synth
+    oc = config.coarse_opt(norm=norm, num_stack=2, hg_depth=3, hg_dim=128, mlp_dim=[129, 1024, 512, 256, 128, 1])
+    of = config.fine_opt(oc, hg_dim=32, mlp_dim=[288, 512, 256, 128, 1], loadSizeBig=128)
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=4, mlp_std=0.16, perturb=True)
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    img64, img128 = synth.synthetic_image(64, 3, seed=2), synth.synthetic_image(128, 3, seed=3)
+    netMR.filter_global(img64)
+    netMR.filter_local(img128[:, None])
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    with torch.no_grad():
+        fc = ref.filter_global(img64).numpy()
+        ff = ref.filter_local(img128).numpy()
+    assert netG.im_feat_list[0].shape == fc.shape == (1, 128, 16, 16) and netMR.im_feat_list[0].shape == ff.shape == (1, 32, 64, 64)
+    ec, ef = _rel(netG.im_feat_list[0].cpu().numpy(), fc), _rel(netMR.im_feat_list[0].cpu().numpy(), ff)
+    observed(f'other_filter_shapes[{norm}]', coarse_rel=ec, fine_rel=ef)
+    assert ec < 2e-4 and ef < 2e-4
+    calib = torch.eye(4)[None]; calib[0, 1, 1] = -1
+    pts = (torch.rand(1, 3, 3000, generator=torch.Generator().manual_seed(5)) * 2 - 1)
+    netMR.query(pts, calib)
+    with torch.no_grad():
+        want = ref.query(pts, calib)[0, 0].numpy()
+    got = netMR.get_preds()[0, 0].cpu().numpy()
+    assert float(np.abs(got - want).max()) < 1e-4

@@ -81,19 +81,28 @@ def test_pointwise_regrouping_is_the_reference_field(observed, flags_name):
     assert np.array_equal(got == 0, want == 0) and err < 1e-4
 
 
+_SHAPES = {
+    # a three-layer coarse MLP merging after its layer 1 - the 128-wide layer in front of the Cout = 1 layer, which is therefore
+    # NOT taken into that layer's epilogue (its output is phi) - and a fine MLP whose last two hidden layers are 128 wide
+    'short': dict(coarse=[257, 512, 128, 1], coarse_res=[1], merge=1, fine=[144, 256, 128, 128, 1], fine_res=[1, 2]),
+    # the published widths with phi taken one layer earlier: phi is the 512-wide layer the depth walk produces
+    # merge_layer -1 = the MLP's own default, len(dims) // 2 = layer 3 (MLP.py:25): phi is the 128-wide layer in front of the last one
+    'merge_default': dict(coarse=[257, 1024, 512, 256, 128, 1], coarse_res=[2, 3, 4], merge=-1, fine=[144, 512, 256, 128, 1], fine_res=[1, 2]),
+    'merge1': dict(coarse=[257, 1024, 512, 256, 128, 1], coarse_res=[2, 3, 4], merge=1, fine=[528, 512, 256, 128, 1], fine_res=[1, 2]),
+}
+
+
+@pytest.mark.parametrize('shape', sorted(_SHAPES))
 @pytest.mark.parametrize('mlp_norm', ['no', 'group'])
-def test_other_mlp_shapes_are_the_reference_field(observed, mlp_norm):
-    """MLP shapes other than the published ones (`options.py:96-108` are options, not constants): a three-layer coarse MLP
-    [257, 512, 128, 1] merging after its layer 1 and a fine MLP [144, 256, 128, 128, 1].  Without norms the 128-wide layer in front
-    of the Cout = 1 layer takes that layer into its epilogue from layer 1 of a three-layer MLP; with GroupNorm nothing is fused."""
+def test_other_mlp_shapes_are_the_reference_field(observed, mlp_norm, shape):
+    """MLP shapes other than the published ones (`options.py:96-108` are options, not constants), with and without norm layers,
+    against the CPU oracle evaluating the reference's 5 000-point query() calls."""
     from oracle import pifu_oracle as O
     from pifuhd_amd import _lib, config, mesh_util, nets, synth
-    oc = config.coarse_opt(mlp_norm=mlp_norm, mlp_dim=[257, 512, 128, 1], mlp_res_layers=[1], merge_layer=1)
-    of = config.fine_opt(oc, mlp_dim=[144, 256, 128, 128, 1], mlp_res_layers=[1, 2])
-    spec = {}
-    synth.mlp_keys('netG.mlp', oc.mlp_dim, oc.mlp_res_layers, oc.mlp_norm, spec)
-    synth.mlp_keys('mlp', of.mlp_dim, of.mlp_res_layers, of.mlp_norm, spec)
-    sd = synth.name_seeded_state_dict(spec, seed=11, mlp_std=0.10 if mlp_norm == 'no' else 0.16, perturb=True)
+    sh = _SHAPES[shape]
+    oc = config.coarse_opt(mlp_norm=mlp_norm, mlp_dim=sh['coarse'], mlp_res_layers=sh['coarse_res'], merge_layer=sh['merge'])
+    of = config.fine_opt(oc, mlp_dim=sh['fine'], mlp_res_layers=sh['fine_res'])
+    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=11, mlp_std=0.10 if mlp_norm == 'no' else 0.16, perturb=True)
     netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
     fc, ff = seeded_features(7)
     netG.set_features(fc)
@@ -114,7 +123,7 @@ def test_other_mlp_shapes_are_the_reference_field(observed, mlp_norm):
     for name, flags in (('default', 0), ('canonical', _lib.Q_NO_COLUMN_SHARING)):
         got = _eval(netMR, res, 0, n, 5000, flags | _lib.Q_FULL_COARSE).cpu().numpy()
         err = float(np.abs(got - want).max())
-        observed(f'other_mlp_shapes[{mlp_norm},{name}]', gpu_vs_oracle=err, field_std=float(want[want > 0].std()))
+        observed(f'other_mlp_shapes[{shape},{mlp_norm},{name}]', gpu_vs_oracle=err, field_std=float(want[want > 0].std()))
         assert np.array_equal(got == 0, want == 0) and err < 1e-4
     assert want[want > 0].std() > 0.01
 
