@@ -11,10 +11,13 @@ from helpers import calib_tensor, golden_nets, seeded_features
 pytestmark = pytest.mark.gpu
 
 
-def test_gen_mesh_end_to_end(tmp_path):
+@pytest.mark.parametrize('configuration', ['default', 'pifuhd_pt'])
+def test_gen_mesh_end_to_end(tmp_path, configuration):
+    """`configuration` 'pifuhd_pt': GroupNorm filters and an MLP without norm layers - what the published checkpoint's opt
+    selects (`reconstruction.py:260-268`, `MLP.py:37-41`)."""
     from oracle import pifu_oracle as O
     from pifuhd_amd import nets, reconstruction, synth
-    sd, oc, of = golden_nets()
+    sd, oc, of = golden_nets() if configuration == 'default' else golden_nets(mlp_norm='no', norm='group', mlp_std=0.10)
     of.loadSizeBig = 128
     netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
     data = {'name': 't', 'img': synth.synthetic_image(128, 3, seed=3), 'img_512': synth.synthetic_image(64, 3, seed=2),

@@ -684,6 +684,36 @@ def test_calc_normal_with_pixel_tables():
     assert np.median(cos) > 0.9999 and (cos > 0.99).mean() > 0.9
 
 
+@pytest.mark.parametrize('mlp_norm', ['no', 'batch'])
+def test_calc_normal_occupancies_other_norms(observed, mlp_norm):
+    """calc_normal's 4n occupancies [p, p+dx, p+dy, p+dz] BY VALUE against the CPU oracle where the MLP carries no norm layers
+    (the published pifuhd.pt: the Cout = 1 layers run in the GEMM epilogues, on the pixel-table path with the skip input as a
+    per-row start value) and with BatchNorm; per-point path and pixel tables."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib
+    netG, netMR, sd, oc, of = _build(mlp_norm)
+    calib = calib_tensor()
+    n = 3000
+    pts = seeded_points(6, n, lim=0.9)
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    stack = [pts.clone() for _ in range(4)]
+    for a in range(3):
+        stack[a + 1][:, a, :] += 0.001
+    with torch.no_grad():
+        want = ref.query(torch.stack(stack, 3).reshape(1, 3, 4 * n), calib, mask_fine=False).reshape(-1).numpy()
+    for name, mode in (('per_point', _lib.PIX_OFF), ('pixel_tables', _lib.PIX_ALWAYS)):
+        _pixel_tables(netMR, mode)
+        try:
+            netMR.calc_normal(pts[:, None], calib[:, None], calib, keep_pred=True)
+            got = netMR.nml_preds.reshape(-1).cpu().numpy()
+        finally:
+            _pixel_tables(netMR, _lib.PIX_AUTO)
+        err = float(np.abs(got - want).max())
+        observed(f'calc_normal_occupancies[{mlp_norm},{name}]', gpu_vs_oracle=err)
+        assert err < 1e-4, (name, err)
+
+
 def test_workspace_limit_runs_smaller_batches_with_identical_results():
     """`pifu_set_workspace_limit`: a call whose batch of launches would need more workspace than the bound runs in more,
     smaller batches of whole chunks - bit-identical results on the lattice path (column sharing + depth walk), on explicit
