@@ -81,6 +81,32 @@ def test_pointwise_regrouping_is_the_reference_field(observed, flags_name):
     assert np.array_equal(got == 0, want == 0) and err < 1e-4
 
 
+@pytest.mark.parametrize('res', [(5, 7, 9), (3, 4, 131), (2, 3, 257), (1, 1, 5), (16, 16, 1)])
+def test_pointwise_regrouping_on_ragged_lattices(res):
+    """Lattices whose columns do not divide anything: 9, 131 (lcm with the 128-row tile 16 768: one group), 257 nodes per column,
+    a single column of 5, columns of ONE node; default path (column sharing + depth walk where it applies) and the per-point path
+    against the CPU oracle, the last group ragged in every case."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib, mesh_util
+    netG, netMR, sd, oc, of = _build('no', mlp_std=0.10)
+    n = res[0] * res[1] * res[2]
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    calib = calib_tensor()
+    _, calib_inv = mesh_util.calib_pair(calib)
+    pts = torch.from_numpy(O.grid_points_rect(res, calib_inv, np.arange(n, dtype=np.int64)).astype(np.float32))[None]
+    with torch.no_grad():
+        want = ref.query(pts, calib)[0, 0].numpy()
+    for flags in (0, _lib.Q_NO_DEPTH_WALK, _lib.Q_NO_COLUMN_SHARING):
+        got = _eval(netMR, res, 0, n, 5000, flags | _lib.Q_FULL_COARSE).cpu().numpy()
+        assert np.array_equal(got == 0, want == 0) and float(np.abs(got - want).max()) < 1e-4, flags
+    # a range that starts and ends inside columns
+    if n > 7:
+        first, count = 3, n - 5
+        got = _eval(netMR, res, first, count, 5000, _lib.Q_FULL_COARSE).cpu().numpy()
+        assert float(np.abs(got - want[first:first + count]).max()) < 1e-4
+
+
 _SHAPES = {
     # a three-layer coarse MLP merging after its layer 1 - the 128-wide layer in front of the Cout = 1 layer, which is therefore
     # NOT taken into that layer's epilogue (its output is phi) - and a fine MLP whose last two hidden layers are 128 wide

@@ -200,6 +200,38 @@ def test_ragged_sizes_vs_oracle(n):
         assert np.abs(got - want).max() < TOL
 
 
+@pytest.mark.parametrize('n', [1, 127, 128, 129, 5001, 16385])
+def test_ragged_sizes_without_norm_layers(n):
+    """The same tile-boundary sizes where the MLP carries no norm layers (the Cout = 1 layers run in the GEMM epilogues: rows of
+    a partly filled 128-row tile must neither be written nor read), per point and through the pixel tables; 16 385 = one row more
+    than the library's own group of 16 384."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import _lib
+    netG, netMR, sd, oc, of = _build('no')
+    pts = seeded_points(60 + n, n, lim=1.05)
+    calib = calib_tensor()
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    ref.feat_coarse, ref.feat_fine = seeded_features(7)
+    with torch.no_grad():
+        want = ref.query(pts, calib)[0, 0].numpy()
+    import ctypes as C
+    from pifuhd_amd.nets import _ptr, _stream_ptr
+    calib_np = np.ascontiguousarray(calib[0].numpy())
+    pts_dev = pts.cuda().contiguous()
+    for mode in (_lib.PIX_OFF, _lib.PIX_ALWAYS):
+        _pixel_tables(netMR, mode)
+        try:
+            out = torch.full((n + 256,), -7.0, device='cuda')          # the rows behind the caller's n stay the caller's
+            _lib.call('pifu_query', netMR._ctx.h, _ptr(pts_dev), n, calib_np.ctypes.data_as(C.c_void_p), n, 0, _ptr(out), None,
+                      None, _stream_ptr(netMR.device))
+            torch.cuda.synchronize()
+        finally:
+            _pixel_tables(netMR, _lib.PIX_AUTO)
+        got = out[:n].cpu().numpy()
+        assert np.abs(got - want).max() < TOL, (mode, float(np.abs(got - want).max()))
+        assert bool((out[n:] == -7.0).all())
+
+
 def test_empty_and_bad_arguments():
     import ctypes as C
     from pifuhd_amd import _lib
