@@ -230,7 +230,8 @@ PIFU_API int pifu_query(pifu_ctx *ctx, const float *points, int64_t n, const flo
  * point's result does not depend on the query() call it is evaluated in, so `chunk` only says how the reference would CUT the
  * work, and the library regroups it: lattice calls (pifu_eval_lattice, pifu_eval_grid) always, point lists (pifu_query,
  * pifu_calc_normal_chunked) when they span more than one chunk.  Groups of PIFU_POINTWISE_CHUNK rows - for a dense lattice
- * range the nearest multiple of lcm(128, res[2]), i.e. whole GEMM tiles and whole lattice columns - with no padding rows, no
+ * range the nearest multiple of lcm(128, res[2]), i.e. whole GEMM tiles and whole lattice columns (tiles only where that lcm
+ * exceeds 4 groups, e.g. 1 021 nodes per column) - with no padding rows, no
  * statistics passes, and depth-walk segments that are complete columns.  Same numbers as the reference's cut up to fp32
  * summation order (the depth walk restarts at group boundaries).  The grouping of a lattice call is a function of
  * (chunk, res[2], the norms) alone and is cut relative to `first`; pifu_effective_chunk returns it (`chunk` itself when a norm

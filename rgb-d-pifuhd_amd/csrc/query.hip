@@ -2006,6 +2006,9 @@ static int64_t effective_chunk(const pifu_ctx *ctx, int64_t chunk, int64_t n, in
         int64_t a = BM, b = res2;
         while (b) { const int64_t t = a % b; a = b; b = t; }
         unit = (int64_t)BM / a * res2;
+        // columns whose lcm with the tile is far beyond the group size (1 021 nodes: 130 688 rows) are cut like a point list:
+        // whole columns are a convenience of the depth walk, whole tiles are what the grouping is for
+        if (unit > 4 * (int64_t)PIFU_POINTWISE_CHUNK) unit = BM;
     }
     int64_t k = (PIFU_POINTWISE_CHUNK + unit / 2) / unit;
     return unit * (k < 1 ? 1 : k);

@@ -49,6 +49,7 @@ def test_effective_chunk_follows_the_norms():
     assert pdist.effective_chunk(net_no._ctx, 5000, 256) == 16384 and pdist.effective_chunk(net_no._ctx, 100000, 512) == 16384
     assert pdist.effective_chunk(net_no._ctx, 5000, 48) == 43 * 384          # lcm(128, 48) = 384: whole tiles AND whole columns
     assert pdist.effective_chunk(net_no._ctx, 5000, 100) == 5 * 3200
+    assert pdist.effective_chunk(net_no._ctx, 5000, 500) == 16000 and pdist.effective_chunk(net_no._ctx, 5000, 513) == 16384 and pdist.effective_chunk(net_no._ctx, 5000, 1021) == 16384          # lcm 130 688: tiles only
     assert pdist.effective_chunk(net_bn._ctx, 5000, 256) == 5000
     assert pdist.effective_chunk(net_bn._ctx, 5000, 256, _lib.Q_COARSE_ONLY) == 16384
 
@@ -81,10 +82,10 @@ def test_pointwise_regrouping_is_the_reference_field(observed, flags_name):
     assert np.array_equal(got == 0, want == 0) and err < 1e-4
 
 
-@pytest.mark.parametrize('res', [(5, 7, 9), (3, 4, 131), (2, 3, 257), (1, 1, 5), (16, 16, 1)])
+@pytest.mark.parametrize('res', [(5, 7, 9), (3, 4, 131), (2, 3, 257), (1, 1, 5), (16, 16, 1), (2, 9, 1021)])
 def test_pointwise_regrouping_on_ragged_lattices(res):
     """Lattices whose columns do not divide anything: 9, 131 (lcm with the 128-row tile 16 768: one group), 257 nodes per column,
-    a single column of 5, columns of ONE node; default path (column sharing + depth walk where it applies) and the per-point path
+    1 021 (lcm 130 688: the groups cut the columns), a single column of 5, columns of ONE node; default path (column sharing + depth walk where it applies) and the per-point path
     against the CPU oracle, the last group ragged in every case."""
     from oracle import pifu_oracle as O
     from pifuhd_amd import _lib, mesh_util
