@@ -108,6 +108,29 @@ def test_pointwise_regrouping_on_ragged_lattices(res):
         assert float(np.abs(got - want[first:first + count]).max()) < 1e-4
 
 
+@pytest.mark.parametrize('precision,bound', [(1, 1e-4), (2, 3e-5)])
+def test_split_precision_on_the_regrouped_lattice(precision, bound):
+    """The opt-in split products (1: bf16 x 3, 2: fp16 x 3; `pifu_set_precision`) where the MLP carries no norm layers: lattice
+    evaluation in the library's own groups - column tables, depth walk, no statistics, the Cout = 1 layers as launches of their
+    own (the fused epilogues are exact-fp32 only) - and an index list, against the exact-fp32 run of the same call."""
+    from pifuhd_amd import _lib
+    netG, netMR, *_ = _build('no', mlp_std=0.10)
+    res = (24, 32, 48)
+    n = res[0] * res[1] * res[2]
+    index = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < 0.4).nonzero()[:, 0].to('cuda', torch.int64).contiguous()
+    exact = _eval(netMR, res, 0, n, 5000, _lib.Q_FULL_COARSE)
+    exact_l = _eval(netMR, res, 0, int(index.numel()), 5000, index=index)
+    _lib.call('pifu_set_precision', netMR._ctx.h, precision)
+    try:
+        got = _eval(netMR, res, 0, n, 5000, _lib.Q_FULL_COARSE)
+        got_l = _eval(netMR, res, 0, int(index.numel()), 5000, index=index)
+    finally:
+        _lib.call('pifu_set_precision', netMR._ctx.h, 0)
+    d, dl = float((got - exact).abs().max()), float((got_l - exact_l).abs().max())
+    assert 0 < d < bound and 0 < dl < bound, (d, dl)
+    assert torch.equal(_eval(netMR, res, 0, n, 5000, _lib.Q_FULL_COARSE), exact)          # and back to exact fp32
+
+
 _SHAPES = {
     # a three-layer coarse MLP merging after its layer 1 - the 128-wide layer in front of the Cout = 1 layer, which is therefore
     # NOT taken into that layer's epilogue (its output is phi) - and a fine MLP whose last two hidden layers are 128 wide
