@@ -422,3 +422,27 @@ def test_other_filter_shapes(norm, observed):
         want = ref.query(pts, calib)[0, 0].numpy()
     got = netMR.get_preds()[0, 0].cpu().numpy()
     assert float(np.abs(got - want).max()) < 1e-4
+
+
+@pytest.mark.parametrize('coarse_px,fine_px', [(96, 192), (192, 384)])
+def test_other_image_sizes(coarse_px, fine_px, observed):
+    """Image sizes between the tiny and the full-size goldens, not powers of two (feature maps of 24 / 96 and 48 / 192 pixels:
+    partly filled tiles in every convolution, odd split-K shapes, the normal maps upsampled by 2 with align_corners): both
+    levels against the CPU oracle."""
+    from oracle import pifu_oracle as O
+    from pifuhd_amd import nets, synth
+    sd, oc, of = golden_nets()
+    of.loadSizeBig = fine_px
+    netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
+    img_c, img_f = synth.synthetic_image(coarse_px, 3, seed=2), synth.synthetic_image(fine_px, 3, seed=3)
+    netMR.filter_global(img_c)
+    netMR.filter_local(img_f[:, None])
+    ref = O.OracleNets(sd, oc, of, fine_training=True)
+    with torch.no_grad():
+        fc = ref.filter_global(img_c).numpy()
+        ff = ref.filter_local(img_f).numpy()
+    assert _rel(netG.nmlF.cpu().numpy(), ref.nmlF.numpy()) < 2e-4 and _rel(netG.nmlB.cpu().numpy(), ref.nmlB.numpy()) < 2e-4
+    ec, ef = _rel(netG.im_feat_list[0].cpu().numpy(), fc), _rel(netMR.im_feat_list[0].cpu().numpy(), ff)
+    observed(f'other_image_sizes[{coarse_px},{fine_px}]', coarse_rel=ec, fine_rel=ef)
+    assert fc.shape == (1, 256, coarse_px // 4, coarse_px // 4) and ff.shape == (1, 16, fine_px // 2, fine_px // 2)
+    assert ec < 5e-4 and ef < 5e-4
