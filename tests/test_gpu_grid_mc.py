@@ -190,6 +190,27 @@ def test_octree_bookkeeping_bit_exact(golden_dir, R, init):
     assert np.array_equal(np.array(counts), gold[f'oct_{R}_{init}_chunks'])
 
 
+@pytest.mark.parametrize('R,init', [(96, 16), (48, 16), (80, 16), (56, 8), (50, 7), (72, 24)])
+def test_octree_bookkeeping_bit_exact_at_other_ratios(golden_dir, R, init):
+    """resolution / init_resolution not a power of two (`--resolution 384 / 320 / 448 / 500` with the fixed init_resolution 64:
+    the step halves through odd values, 50 // 7 leaves a remainder): the float64 SDF and the per-call point counts of the
+    reference (`octree_ratios.npz`, generated by importing it: tests/golden/make_golden_r6.py)."""
+    from pifuhd_amd import mesh_util
+    gold = np.load(os.path.join(golden_dir, 'octree_ratios.npz'))
+    coords, _ = mesh_util.create_grid(R, R, R)
+    calib_inv = np.linalg.inv(np.diag([1.0, -1.0, 1.0, 1.0]))
+    c = coords.reshape(3, -1).T
+    c = np.matmul(np.concatenate([c, np.ones((c.shape[0], 1))], 1), calib_inv.T)[:, :3].T.reshape(3, R, R, R)
+    counts = []
+
+    def f(p):
+        counts.append(p.shape[1])
+        return noisy_field(p)
+    sdf = mesh_util.eval_grid_octree(c, f, init_resolution=init, threshold=0.05, num_samples=5000)
+    assert hashlib.sha256(sdf.tobytes()).digest() == gold[f'oct_{R}_{init}_sha'].tobytes()
+    assert np.array_equal(np.array(counts), gold[f'oct_{R}_{init}_chunks'])
+
+
 def test_network_grid_vs_reference_sdf(golden_dir):
     """Dense 32^3 and octree 64^3 with the network field: SDF within 1e-4 of the reference's, and the
     triangle index stream bit-exact against the serial oracle run on the SAME device SDF."""
@@ -567,12 +588,13 @@ def test_full_size_marching_cubes_properties(ctx):
     assert torch.equal(f, f2) and torch.equal(v.view(torch.int32), v2.view(torch.int32))
 
 
-@pytest.mark.parametrize('init', [64, 16])
-def test_multi_level_network_octree_composition_vs_oracle(init):
+@pytest.mark.parametrize('R,init,n_levels', [(128, 64, 2), (128, 16, 4), (96, 16, 3)])
+def test_multi_level_network_octree_composition_vs_oracle(R, init, n_levels):
     """The COMPOSITION `pifu_eval_grid` runs for gen_mesh - several octree levels, each level's points chosen from the SDF
     the previous levels left, evaluated by the network (column sharing, depth walk, 5000-point GroupNorm chunks cut from
     the level's own index list), committed and block-filled - against the same composition on the CPU oracle
-    (`mesh_util.py:124-187` + `PIFuMRNet.query`): R = 128 with init_resolution 64 (two levels) and 16 (four levels).  The
+    (`mesh_util.py:124-187` + `PIFuMRNet.query`): R = 128 with init_resolution 64 (two levels) and 16 (four levels), R = 96 with
+    init_resolution 16 (steps 6, 3, 1: what `--resolution 384` does with the fixed init_resolution 64).  The
     levels must select the same number of points, the float64 SDF must agree within the north star's 1e-4, the fused
     device loop must equal the level-by-level ABI calls bit for bit, and marching cubes on the device SDF must be the
     serial oracle's on that SDF, vertices and faces."""
@@ -580,7 +602,7 @@ def test_multi_level_network_octree_composition_vs_oracle(init):
     from oracle import pifu_oracle as O
     from pifuhd_amd import _lib, mesh_util, nets
     from pifuhd_amd.nets import _ptr, _stream_ptr
-    R, chunk = 128, 5000
+    chunk = 5000
     sd, oc, of = golden_nets()
     netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
     fc, ff = seeded_features(9)
@@ -602,7 +624,7 @@ def test_multi_level_network_octree_composition_vs_oracle(init):
         want = O.eval_grid_octree(R, cinv, field, chunk, init_resolution=init, stats=stats)
     finally:
         torch.set_num_threads(threads)
-    assert len(stats) == {64: 2, 16: 4}[init] and all(n > 0 for _, n in stats)
+    assert len(stats) == n_levels and all(n > 0 for _, n in stats)
 
     # the fused device loop
     sdf, n_eval = mesh_util.eval_grid_device(netMR, calib_t, R, chunk, True, init_resolution=init)
