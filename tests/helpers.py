@@ -24,15 +24,26 @@ def calib_tensor():
     return c[None]
 
 
+_GOLDEN_NETS = {}
+
+
 def golden_nets(mlp_norm='group', seed=1, mlp_std=0.16, perturb=True, norm='batch'):
-    """Options + name-seeded state dict exactly as make_golden.build_reference() loads them."""
+    """Options + name-seeded state dict exactly as make_golden.build_reference() loads them.  Generating the ~600 seeded tensors
+    takes seconds and most tests ask for the same few sets: kept per process; every caller gets its own dict and its own option
+    objects (tests replace entries and set option fields), the tensors themselves are shared and never written in place."""
+    import copy
+    from collections import OrderedDict
     if mlp_norm not in ('group', 'batch') and mlp_std is not None:
         mlp_std = 0.04
-    oc = config.coarse_opt(mlp_norm=mlp_norm, norm=norm)
-    of = config.fine_opt(oc)
-    sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=seed, mlp_std=mlp_std,
-                                      perturb=perturb)
-    return sd, oc, of
+    key = (mlp_norm, seed, mlp_std, perturb, norm)
+    if key not in _GOLDEN_NETS:
+        oc = config.coarse_opt(mlp_norm=mlp_norm, norm=norm)
+        of = config.fine_opt(oc)
+        sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=seed, mlp_std=mlp_std,
+                                          perturb=perturb)
+        _GOLDEN_NETS[key] = (sd, oc, of)
+    sd, oc, of = _GOLDEN_NETS[key]
+    return OrderedDict(sd), copy.deepcopy(oc), copy.deepcopy(of)
 
 
 def noisy_field(points):

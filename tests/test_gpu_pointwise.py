@@ -13,6 +13,7 @@ import torch
 from helpers import calib_tensor, golden_nets, seeded_features
 
 pytestmark = pytest.mark.gpu
+_SD_CACHE = {}      # seeded state dicts of this module's builds (seconds each; the tensors are never written in place)
 
 
 def _build(mlp_norm, mlp_std=None):
@@ -20,7 +21,9 @@ def _build(mlp_norm, mlp_std=None):
     sd, oc, of = golden_nets(mlp_norm=mlp_norm)
     if mlp_std is not None:      # a field with contrast for the un-normalised MLP (make_golden_r5.py: 0.10)
         oc = config.coarse_opt(mlp_norm=mlp_norm); of = config.fine_opt(oc)
-        sd = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=mlp_std, perturb=True)
+        if (mlp_norm, mlp_std) not in _SD_CACHE:
+            _SD_CACHE[(mlp_norm, mlp_std)] = synth.name_seeded_state_dict(synth.state_dict_spec(oc, of), seed=1, mlp_std=mlp_std, perturb=True)
+        sd = dict(_SD_CACHE[(mlp_norm, mlp_std)])
     netG, netMR = nets.build_nets(oc, of, sd, 'cuda')
     fc, ff = seeded_features(7)
     netG.set_features(fc)
