@@ -24,6 +24,7 @@ ap.add_argument('res', type=int, nargs='?', default=512)
 ap.add_argument('--subject', default='headline', choices=['headline', 'body', 'pt_body'])
 ap.add_argument('--batch-rows', type=int, default=2097152)
 ap.add_argument('--calls', type=int, default=2)
+ap.add_argument('--plain', type=int, default=0, help='also time N calls WITHOUT timings / profiling (no phase-boundary synchronisations): the cost of the instrumentation')
 args = ap.parse_args()
 RES = args.res
 pt = args.subject == 'pt_body'
@@ -67,6 +68,20 @@ with tempfile.TemporaryDirectory() as td:
               '%.3f TFLOP; (%.3f + %.3f) TFLOP / %.4f s / 157.3 TFLOP/s = %.4f of the fp32-matrix peak' %
               (k, g_n, args.batch_rows, g_fl / 1e12, g_ms, e_n, e_fl / 1e12, g_fl / 1e12, e_fl / 1e12, t['total_s'],
                (g_fl + e_fl) / t['total_s'] / 157.3e12), flush=True)
+    if args.plain:
+        for mode in ('instrumented', 'plain', 'instrumented', 'plain'):
+            ts = []
+            for k in range(args.plain):
+                path = os.path.join(td, 'p%d.obj' % k)
+                if mode == 'instrumented':
+                    _lib.call('pifu_profile_enable', netMR._ctx.h, 1)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                recon.gen_mesh(RES, netMR, 'cuda', data, path, timings={} if mode == 'instrumented' else None)
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                _lib.call('pifu_profile_enable', netMR._ctx.h, 0)
+                os.remove(path)
+            ts.sort()
+            print('%-12s gen_mesh wall clock: median %.4f s, min %.4f s (%d calls)' % (mode, ts[len(ts) // 2], ts[0], len(ts)), flush=True)
     # finer breakdown of reconstruction()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     sdf, n = mesh_util.eval_grid_device(netMR, data['calib'], RES, 5000, True); torch.cuda.synchronize(); t1 = time.perf_counter()
